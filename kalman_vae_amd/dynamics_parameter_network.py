@@ -1,0 +1,85 @@
+"""Dynamics-parameter ("weight") networks: (t,B,a_dim) -> softmax (t,B,K).
+
+These stay ordinary PyTorch modules (MIOpen/rocBLAS on the GPU); the HIP
+kernels only consume the mixing weights they emit.  Parameter names match the
+reference (kvae/dynamics_parameter_network.py:18-90) so its checkpoints load:
+``lstm.*`` + ``linear.*`` for the LSTM model, ``layers.<i>.*`` for the MLP.
+"""
+import torch
+import torch.nn as nn
+
+
+class LSTMModel(nn.Module):
+    """nn.LSTM -> Linear -> softmax with the recurrent state cached on the
+    module between calls, so that feeding the sequence one step at a time
+    equals feeding it whole."""
+
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.lstm = nn.LSTM(input_dim, hidden_dim, num_layers=num_layers)
+        self.linear = nn.Linear(hidden_dim, output_dim)
+        self.hidden = None
+        self.count = 0
+
+    def clear_hidden_state(self):
+        self.hidden = None
+        self.count = 0
+
+    def reset_hidden_state(self, batch_size, device, dtype):
+        shape = (self.num_layers, batch_size, self.hidden_dim)
+        self.hidden = (torch.zeros(shape, dtype=dtype, device=device),
+                       torch.zeros(shape, dtype=dtype, device=device))
+        self.count = 0
+
+    def forward(self, x):
+        self.count += 1
+        if self.hidden is None:
+            self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
+        h, self.hidden = self.lstm(x, self.hidden)
+        return torch.softmax(self.linear(h), dim=-1)
+
+    is_recurrent = True
+
+
+class MLPModel(nn.Module):
+    """num_layers Linear layers with ReLU between them, softmax on top."""
+
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        # The first layer always maps to hidden_dim, also when it is the only
+        # layer (dynamics_parameter_network.py:70-76 tests i == 0 first).
+        self.layers = nn.ModuleList()
+        for i in range(num_layers):
+            fan_in = input_dim if i == 0 else hidden_dim
+            fan_out = output_dim if (i == num_layers - 1 and i != 0) else hidden_dim
+            self.layers.append(nn.Linear(fan_in, fan_out))
+
+    def clear_hidden_state(self):
+        pass
+
+    def reset_hidden_state(self, batch_size, device, dtype):
+        pass
+
+    def forward(self, x):
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i != last:
+                x = torch.relu(x)
+        return torch.softmax(x, dim=-1)
+
+    is_recurrent = False
+
+
+def make_weight_model(kind, a_dim, K, hidden_dim, num_layers):
+    if kind == "mlp":
+        return MLPModel(a_dim, K, hidden_dim=hidden_dim, num_layers=num_layers)
+    if kind == "lstm":
+        return LSTMModel(a_dim, K, hidden_dim=hidden_dim, num_layers=num_layers)
+    raise ValueError("Invalid dynamics_parameter_network: {}".format(kind))

@@ -1,0 +1,56 @@
+"""Helpers shared by the tests: load golden fixtures (tests/golden/*.npz, made
+by tests/golden/make_golden.py from the reference) and rebuild their inputs."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names(pattern="*"):
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, pattern + ".npz")))
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.cfg = json.loads(str(z["config"]))
+        self.dtype = torch.float64 if self.cfg["dtype"] == "float64" else torch.float32
+        self.t = {k: torch.from_numpy(np.array(z[k])) for k in z.files if k != "config"}
+
+    def __getitem__(self, key):
+        return self.t[key]
+
+    def has(self, key):
+        return key in self.t
+
+    def weight_model(self):
+        """The package's weight network with the fixture's parameters."""
+        from kalman_vae_amd.dynamics_parameter_network import make_weight_model
+        c = self.cfg
+        net = make_weight_model(c["net"], c["p"], c["K"], c.get("hidden_dim", 8),
+                                c.get("num_layers", 2)).to(self.dtype)
+        sd = {k[len("sd.weight_model."):]: v for k, v in self.t.items()
+              if k.startswith("sd.weight_model.")}
+        net.load_state_dict(sd)
+        return net
+
+    def noise(self, which):
+        """(eps_state, eps_obs) for 'filter' / 'smooth' or None where the
+        fixture ran in "mean" mode."""
+        st = self.cfg["state_transition"] == "sample"
+        ob = self.cfg["observation"] == "sample"
+        return (self.t[f"eps.{which}_state"] if st else None,
+                self.t[f"eps.{which}_obs"] if ob else None)
+
+
+def rel_err(x, ref):
+    x = x.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = ref.abs().max().clamp_min(1e-30)
+    return float((x - ref).abs().max() / scale)
