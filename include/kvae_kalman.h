@@ -1,0 +1,210 @@
+/*
+ * kvae_kalman.h -- C ABI of the MI355X (gfx950) Kalman filter / RTS smoother /
+ * Kalman-ELBO kernels.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream
+ * (passed as void*); nothing here allocates, synchronises with the host or
+ * touches a torch type.  All tensors use the reference's layout: sequence
+ * first, row-major contiguous, e.g. means (T,B,n), covariances (T,B,n,n).
+ * "real" below means float when dims.dtype == KVAE_F32 and double when
+ * KVAE_F64; every pointer of one call has that element type.
+ *
+ * Return value: KVAE_OK or a negative KVAE_E* code (kvae_error_string()).
+ * Numerical failures (a non-positive Cholesky pivot) do not abort a launch;
+ * they OR a bit into the int32 word `status` points to (may be NULL).
+ *
+ * The reference has no FFI layer; the interface each entry point replaces is
+ * a Python method of kvae/state_space_model.py or a block of
+ * kvae/kalman_vae.py and is cited on the declaration.
+ */
+#ifndef KVAE_KALMAN_H
+#define KVAE_KALMAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVAE_ABI_VERSION 1
+
+enum { KVAE_F32 = 0, KVAE_F64 = 1 };
+
+enum {
+    KVAE_OK = 0,
+    KVAE_E_BADARG = -1,      /* null required pointer, T < 1, B < 1 ...          */
+    KVAE_E_UNSUPPORTED = -2, /* (n,p,K,dtype) has no compiled kernel             */
+    KVAE_E_WORKSPACE = -3,   /* workspace smaller than kvae_workspace_bytes()    */
+    KVAE_E_LAUNCH = -4       /* hipGetLastError() after the launch was not ok    */
+};
+
+/* bits of the device status word */
+enum {
+    KVAE_STATUS_NONPD_INNOVATION = 1, /* S = C P C^T + R had a pivot <= 0        */
+    KVAE_STATUS_NONPD_PREDICTED = 2,  /* predicted covariance (smoother inverse)  */
+    KVAE_STATUS_NONPD_SMOOTHED = 4,   /* smoothed covariance (sampling / ELBO)    */
+    KVAE_STATUS_NONPD_NOISE = 8       /* Q, R or the initial covariance           */
+};
+
+typedef struct {
+    int32_t T;          /* steps in this call (a segment of a longer sequence is allowed) */
+    int32_t B;          /* sequences                                             */
+    int32_t n;          /* state dimension  (z_dim)                              */
+    int32_t p;          /* observation dimension (a_dim)                         */
+    int32_t K;          /* number of basis matrices                              */
+    int32_t dtype;      /* KVAE_F32 / KVAE_F64                                   */
+    int32_t symmetrize; /* symmetrize_covariance of the reference                */
+    int32_t burn_in;    /* steps t < burn_in pass no gradient (backward only)    */
+} kvae_dims;
+
+/* ------------------------------------------------------------------------ */
+/* Filter: StateSpaceModel.kalman_filter, kvae/state_space_model.py:172-373
+ * (the recursion of lines 284-352; the imputation sample of lines 232-277 and
+ * the weight network of lines 279-282 stay on the PyTorch side).
+ *
+ * For t = 0..T-1, per sequence b, with A_t = sum_k alpha[t,b,k] A_K[k] and
+ * C_t likewise: measurement update with C_t, mask blend, symmetrise, time
+ * update with A_{t+1}, symmetrise.
+ * The recursion starts from (m_in, P_in): shape (n)/(n,n) shared by all
+ * sequences when carry_per_sequence == 0 (initial_state_mean/covariance), or
+ * (B,n)/(B,n,n) when 1 (continuing a sequence: pass the previous call's
+ * mean_pred[T-1], cov_pred[T-1]).
+ */
+typedef struct {
+    const void *a;        /* (T,B,p)   observations                              */
+    const void *alpha;    /* (T+1,B,K) mixing weights, row t+1 = weights after a_t */
+    const void *mask;     /* (T,B) real in [0,1], or NULL = all observed         */
+    const void *A_K;      /* (K,n,n)                                             */
+    const void *C_K;      /* (K,p,n)                                             */
+    const void *Q;        /* (n,n)                                               */
+    const void *R;        /* (p,p)                                               */
+    const void *m_in;     /* see above                                           */
+    const void *P_in;
+    int32_t carry_per_sequence;
+    int32_t _pad;
+    void *mean_filt;      /* (T,B,n)    z_{t|t}                                  */
+    void *cov_filt;       /* (T,B,n,n)                                           */
+    void *mean_pred;      /* (T,B,n)    z_{t+1|t}                                */
+    void *cov_pred;       /* (T,B,n,n)                                           */
+    void *mat_As;         /* (T+1,B,n,n) or NULL                                 */
+    void *mat_Cs;         /* (T+1,B,p,n) or NULL                                 */
+    int32_t *status;      /* or NULL                                             */
+} kvae_filter_fwd;
+
+int kvae_filter_forward(const kvae_dims *d, const kvae_filter_fwd *io, void *stream);
+
+/* Adjoint of kvae_filter_forward (the reference differentiates lines 172-373
+ * with the autograd tape; there is no hand-written counterpart).  Needs the
+ * forward's inputs and its four mean/cov outputs.  Upstream gradients may be
+ * NULL (= zero).  g_carry_* are the gradients w.r.t. mean_pred[T-1] /
+ * cov_pred[T-1] arriving from a following segment.  Parameter gradients are
+ * overwritten, not accumulated.
+ */
+typedef struct {
+    kvae_filter_fwd fwd;          /* same pointers as the forward call           */
+    const void *g_mean_filt, *g_cov_filt, *g_mean_pred, *g_cov_pred;
+    const void *g_mat_As, *g_mat_Cs;   /* (T+1,...) */
+    void *d_a;            /* (T,B,p)                                             */
+    void *d_alpha;        /* (T+1,B,K)                                           */
+    void *d_m_in;         /* (B,n)   per-sequence, also when the carry is shared */
+    void *d_P_in;         /* (B,n,n)                                             */
+    void *d_A_K;          /* (K,n,n)  summed over T and B                        */
+    void *d_C_K;          /* (K,p,n)                                             */
+    void *d_Q;            /* (n,n)                                               */
+    void *d_R;            /* (p,p)                                               */
+} kvae_filter_bwd;
+
+int kvae_filter_backward(const kvae_dims *d, const kvae_filter_bwd *io,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Smoother: StateSpaceModel.kalman_smooth, kvae/state_space_model.py:375-484.
+ * Reverse-time RTS recursion plus the per-step draw z_t = mean + chol(cov) eps
+ * and re-emission a_t = C_t z_t + chol(R) eps'.  eps_state / eps_obs are
+ * standard-normal draws indexed by time step, NULL selects the "mean" mode.
+ * LR = chol(R) is only read when eps_obs != NULL.
+ */
+typedef struct {
+    const void *mean_filt, *cov_filt, *mean_pred, *cov_pred; /* filter outputs  */
+    const void *mat_As;   /* (T+1,B,n,n)                                         */
+    const void *mat_Cs;   /* (T+1,B,p,n)                                         */
+    const void *LR;       /* (p,p) lower Cholesky factor of R, or NULL           */
+    const void *eps_state;/* (T,B,n) or NULL                                     */
+    const void *eps_obs;  /* (T,B,p) or NULL                                     */
+    void *mean_smooth;    /* (T,B,n)                                             */
+    void *cov_smooth;     /* (T,B,n,n)                                           */
+    void *zs;             /* (T,B,n)                                             */
+    void *as_resampled;   /* (T,B,p)                                             */
+    int32_t *status;
+} kvae_smooth_fwd;
+
+int kvae_smooth_forward(const kvae_dims *d, const kvae_smooth_fwd *io, void *stream);
+
+typedef struct {
+    kvae_smooth_fwd fwd;
+    const void *g_mean_smooth, *g_cov_smooth, *g_zs, *g_as_resampled; /* or NULL */
+    void *d_mean_filt, *d_cov_filt, *d_mean_pred, *d_cov_pred;        /* (T,B,..) */
+    void *d_mat_As;       /* (T+1,B,n,n)                                         */
+    void *d_mat_Cs;       /* (T+1,B,p,n)                                         */
+    void *d_LR;           /* (p,p) summed over T and B, or NULL                  */
+} kvae_smooth_bwd;
+
+int kvae_smooth_backward(const kvae_dims *d, const kvae_smooth_bwd *io,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Kalman ELBO terms: kvae/kalman_vae.py:165-168,191-242, before `aggregate`.
+ * z_t = mean_smooth_t + chol(cov_smooth_t) eps_t;
+ * obs[t,b]   = log N(a_t; C_t z_t, R)                 (C_0..C_{T-1})
+ * trans[0,b] = log N(z_0; m0, P0); trans[t,b] = log N(z_t; A_t z_{t-1}, Q)
+ * post[t,b]  = log N(z_t; mean_smooth_t, cov_smooth_t)
+ */
+typedef struct {
+    const void *a;           /* (T,B,p)                                          */
+    const void *mean_smooth; /* (T,B,n)                                          */
+    const void *cov_smooth;  /* (T,B,n,n)                                        */
+    const void *mat_As;      /* (T+1,B,n,n)                                      */
+    const void *mat_Cs;      /* (T+1,B,p,n)                                      */
+    const void *Q, *R;       /* (n,n), (p,p)                                     */
+    const void *m0, *P0;     /* (n), (n,n)                                       */
+    const void *eps;         /* (T,B,n)                                          */
+    void *obs, *trans, *post;/* (T,B) each                                       */
+    void *z;                 /* (T,B,n) the sample, or NULL                      */
+    int32_t *status;
+} kvae_elbo_fwd;
+
+int kvae_elbo_forward(const kvae_dims *d, const kvae_elbo_fwd *io, void *stream);
+
+typedef struct {
+    kvae_elbo_fwd fwd;
+    const void *g_obs, *g_trans, *g_post; /* (T,B) upstream gradients, or NULL   */
+    void *d_a;            /* (T,B,p)                                             */
+    void *d_mean_smooth;  /* (T,B,n)                                             */
+    void *d_cov_smooth;   /* (T,B,n,n)                                           */
+    void *d_mat_As;       /* (T+1,B,n,n)                                         */
+    void *d_mat_Cs;       /* (T+1,B,p,n)                                         */
+    void *d_Q, *d_R;      /* summed over T and B                                 */
+    void *d_m0, *d_P0;    /* summed over B                                       */
+} kvae_elbo_bwd;
+
+int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ */
+enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };
+
+/* Scratch bytes the backward entry points need for their per-wave partial
+ * sums of the parameter gradients (0 for an unknown op).                     */
+size_t kvae_workspace_bytes(const kvae_dims *d, int op);
+
+/* 1 when a kernel for (n,p,K,dtype) is compiled in.                          */
+int kvae_supported(int n, int p, int K, int dtype);
+
+int kvae_version(void);
+const char *kvae_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVAE_KALMAN_H */

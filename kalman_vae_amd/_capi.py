@@ -1,0 +1,160 @@
+"""ctypes mirror of include/kvae_kalman.h and the loader of the HIP library.
+
+The library (kalman_vae_amd/csrc/libkvae_kalman.so, built by csrc/Makefile or
+``__graft_entry__.build()``) is the only compute backend.  There is no CPU
+path: if the library is missing or a tensor is not on a GPU the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkvae_kalman.so")
+
+KVAE_F32, KVAE_F64 = 0, 1
+OP_FILTER_BWD, OP_SMOOTH_BWD, OP_ELBO_BWD = 1, 2, 3
+
+STATUS_BITS = {
+    1: "innovation covariance C P C^T + R is not positive definite",
+    2: "predicted covariance is not positive definite",
+    4: "smoothed covariance is not positive definite",
+    8: "Q, R or the initial covariance is not positive definite",
+}
+
+_vp = C.c_void_p
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("T", "B", "n", "p", "K", "dtype", "symmetrize", "burn_in")]
+
+
+def _ptr_struct(name, fields):
+    """Structure whose members are all void* except those given as (name, ctype)."""
+    fl = []
+    for f in fields:
+        fl.append(f if isinstance(f, tuple) else (f, _vp))
+    return type(name, (C.Structure,), {"_fields_": fl})
+
+
+FilterFwd = _ptr_struct("FilterFwd", [
+    "a", "alpha", "mask", "A_K", "C_K", "Q", "R", "m_in", "P_in",
+    ("carry_per_sequence", C.c_int32), ("_pad", C.c_int32),
+    "mean_filt", "cov_filt", "mean_pred", "cov_pred", "mat_As", "mat_Cs", "status"])
+FilterBwd = _ptr_struct("FilterBwd", [
+    ("fwd", FilterFwd), "g_mean_filt", "g_cov_filt", "g_mean_pred", "g_cov_pred",
+    "g_mat_As", "g_mat_Cs", "d_a", "d_alpha", "d_m_in", "d_P_in",
+    "d_A_K", "d_C_K", "d_Q", "d_R"])
+SmoothFwd = _ptr_struct("SmoothFwd", [
+    "mean_filt", "cov_filt", "mean_pred", "cov_pred", "mat_As", "mat_Cs", "LR",
+    "eps_state", "eps_obs", "mean_smooth", "cov_smooth", "zs", "as_resampled", "status"])
+SmoothBwd = _ptr_struct("SmoothBwd", [
+    ("fwd", SmoothFwd), "g_mean_smooth", "g_cov_smooth", "g_zs", "g_as_resampled",
+    "d_mean_filt", "d_cov_filt", "d_mean_pred", "d_cov_pred", "d_mat_As", "d_mat_Cs", "d_LR"])
+ElboFwd = _ptr_struct("ElboFwd", [
+    "a", "mean_smooth", "cov_smooth", "mat_As", "mat_Cs", "Q", "R", "m0", "P0", "eps",
+    "obs", "trans", "post", "z", "status"])
+ElboBwd = _ptr_struct("ElboBwd", [
+    ("fwd", ElboFwd), "g_obs", "g_trans", "g_post", "d_a", "d_mean_smooth", "d_cov_smooth",
+    "d_mat_As", "d_mat_Cs", "d_Q", "d_R", "d_m0", "d_P0"])
+
+EXPORTS = (
+    "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
+    "kvae_filter_forward", "kvae_filter_backward",
+    "kvae_smooth_forward", "kvae_smooth_backward",
+    "kvae_elbo_forward", "kvae_elbo_backward",
+)
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor passed to the Kalman kernels must be contiguous")
+    return t.data_ptr()
+
+
+def fill(struct, **tensors):
+    for k, v in tensors.items():
+        if isinstance(v, int):
+            setattr(struct, k, v)
+        else:
+            setattr(struct, k, ptr(v))
+    return struct
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return KVAE_F32
+    if dtype == torch.float64:
+        return KVAE_F64
+    raise TypeError(f"Kalman kernels support float32 and float64, got {dtype}")
+
+
+_lib = None
+
+
+def declare(lib, prefix="kvae_", with_stream=True):
+    """Set argtypes/restype for the six compute entry points of `lib`."""
+    tail = [_vp] if with_stream else []
+    ws = [_vp, C.c_size_t]
+    spec = {
+        "filter_forward": [C.POINTER(Dims), C.POINTER(FilterFwd)] + tail,
+        "filter_backward": [C.POINTER(Dims), C.POINTER(FilterBwd)] + (ws + tail if with_stream else []),
+        "smooth_forward": [C.POINTER(Dims), C.POINTER(SmoothFwd)] + tail,
+        "smooth_backward": [C.POINTER(Dims), C.POINTER(SmoothBwd)] + (ws + tail if with_stream else []),
+        "elbo_forward": [C.POINTER(Dims), C.POINTER(ElboFwd)] + tail,
+        "elbo_backward": [C.POINTER(Dims), C.POINTER(ElboBwd)] + (ws + tail if with_stream else []),
+    }
+    for name, argtypes in spec.items():
+        fn = getattr(lib, prefix + name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+def load():
+    """Load libkvae_kalman.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP library {LIB_PATH} not found: build it with "
+            "`make -C kalman_vae_amd/csrc` (or __graft_entry__.build()). "
+            "kalman_vae_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    declare(lib)
+    lib.kvae_version.restype = C.c_int
+    lib.kvae_error_string.restype = C.c_char_p
+    lib.kvae_error_string.argtypes = [C.c_int]
+    lib.kvae_supported.argtypes = [C.c_int] * 4
+    lib.kvae_supported.restype = C.c_int
+    lib.kvae_workspace_bytes.argtypes = [C.POINTER(Dims), C.c_int]
+    lib.kvae_workspace_bytes.restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError("kvae kernel call failed: "
+                           + load().kvae_error_string(code).decode())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "kalman_vae_amd runs on MI355X only: got a tensor on "
+                f"{t.device}; there is no CPU fallback")
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def status_message(word):
+    return "; ".join(msg for bit, msg in STATUS_BITS.items() if word & bit)

@@ -1,0 +1,182 @@
+// TEST-ONLY host build of the per-sequence device math.
+//
+// kalman_core.h is written so that the code a GPU lane executes for one
+// sequence is an ordinary C++ function.  This file compiles that same source
+// with g++ and runs it in a loop over the batch on the CPU, behind functions
+// that take the structs of include/kvae_kalman.h.  It exists so that the math
+// and the adjoints can be checked against the oracle in a container without a
+// GPU.  It is not part of the package, is never loaded by it, and is not a
+// fallback: kalman_vae_amd refuses to run without its HIP library.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/kvae_kalman.h"
+#include "../../kalman_vae_amd/csrc/kalman_core.h"
+
+using namespace kvae;
+
+namespace {
+
+template <typename R>
+FilterFwdArgs<R> mk(const kvae_dims* d, const kvae_filter_fwd* io) {
+    FilterFwdArgs<R> g;
+    g.T = d->T; g.B = d->B; g.symmetrize = d->symmetrize;
+    g.carry_per_sequence = io->carry_per_sequence;
+    g.a = (const R*)io->a; g.alpha = (const R*)io->alpha; g.mask = (const R*)io->mask;
+    g.A_K = (const R*)io->A_K; g.C_K = (const R*)io->C_K; g.Q = (const R*)io->Q;
+    g.Rm = (const R*)io->R; g.m_in = (const R*)io->m_in; g.P_in = (const R*)io->P_in;
+    g.m = (R*)io->mean_filt; g.Pf = (R*)io->cov_filt; g.mn = (R*)io->mean_pred;
+    g.Pn = (R*)io->cov_pred; g.As = (R*)io->mat_As; g.Cs = (R*)io->mat_Cs;
+    g.status = io->status;
+    return g;
+}
+template <typename R>
+SmoothFwdArgs<R> mk(const kvae_dims* d, const kvae_smooth_fwd* io) {
+    SmoothFwdArgs<R> g;
+    g.T = d->T; g.B = d->B; g.symmetrize = d->symmetrize;
+    g.m = (const R*)io->mean_filt; g.Pf = (const R*)io->cov_filt;
+    g.mn = (const R*)io->mean_pred; g.Pn = (const R*)io->cov_pred;
+    g.As = (const R*)io->mat_As; g.Cs = (const R*)io->mat_Cs; g.LR = (const R*)io->LR;
+    g.eps_s = (const R*)io->eps_state; g.eps_o = (const R*)io->eps_obs;
+    g.ms = (R*)io->mean_smooth; g.Ps = (R*)io->cov_smooth; g.zs = (R*)io->zs;
+    g.ares = (R*)io->as_resampled; g.status = io->status;
+    return g;
+}
+template <typename R>
+ElboFwdArgs<R> mk(const kvae_dims* d, const kvae_elbo_fwd* io) {
+    ElboFwdArgs<R> g;
+    g.T = d->T; g.B = d->B;
+    g.a = (const R*)io->a; g.ms = (const R*)io->mean_smooth; g.Ps = (const R*)io->cov_smooth;
+    g.As = (const R*)io->mat_As; g.Cs = (const R*)io->mat_Cs; g.Q = (const R*)io->Q;
+    g.Rm = (const R*)io->R; g.m0 = (const R*)io->m0; g.P0 = (const R*)io->P0;
+    g.eps = (const R*)io->eps; g.obs = (R*)io->obs; g.trans = (R*)io->trans;
+    g.post = (R*)io->post; g.z = (R*)io->z; g.status = io->status;
+    return g;
+}
+
+template <typename R>
+void put(void* out, const R* src, int len) {
+    if (out) memcpy(out, src, sizeof(R) * len);
+}
+
+template <typename R, int N, int P, int K>
+int filter_fwd(const kvae_dims* d, const kvae_filter_fwd* io) {
+    FilterFwdArgs<R> g = mk<R>(d, io);
+    for (int b = 0; b < d->B; ++b) filter_forward_sequence<R, N, P, K>(g, b);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int filter_bwd(const kvae_dims* d, const kvae_filter_bwd* io) {
+    using PG = FilterParamGrads<N, P, K>;
+    FilterBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_m = (const R*)io->g_mean_filt; g.g_P = (const R*)io->g_cov_filt;
+    g.g_mn = (const R*)io->g_mean_pred; g.g_Pn = (const R*)io->g_cov_pred;
+    g.g_As = (const R*)io->g_mat_As; g.g_Cs = (const R*)io->g_mat_Cs;
+    g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha;
+    g.d_m_in = (R*)io->d_m_in; g.d_P_in = (R*)io->d_P_in; g.partial = nullptr;
+    std::vector<R> acc(PG::LEN, R(0));
+    for (int b = 0; b < d->B; ++b) filter_backward_sequence<R, N, P, K>(g, b, acc.data());
+    put<R>(io->d_A_K, acc.data() + PG::OFF_A, K * N * N);
+    put<R>(io->d_C_K, acc.data() + PG::OFF_C, K * P * N);
+    put<R>(io->d_Q, acc.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, acc.data() + PG::OFF_R, P * P);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int smooth_fwd(const kvae_dims* d, const kvae_smooth_fwd* io) {
+    SmoothFwdArgs<R> g = mk<R>(d, io);
+    for (int b = 0; b < d->B; ++b) smooth_forward_sequence<R, N, P>(g, b);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int smooth_bwd(const kvae_dims* d, const kvae_smooth_bwd* io) {
+    SmoothBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_ms = (const R*)io->g_mean_smooth; g.g_Ps = (const R*)io->g_cov_smooth;
+    g.g_zs = (const R*)io->g_zs; g.g_ares = (const R*)io->g_as_resampled;
+    g.d_m = (R*)io->d_mean_filt; g.d_P = (R*)io->d_cov_filt; g.d_mn = (R*)io->d_mean_pred;
+    g.d_Pn = (R*)io->d_cov_pred; g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs;
+    g.partial = nullptr;
+    std::vector<R> acc(P * P, R(0));
+    for (int b = 0; b < d->B; ++b) smooth_backward_sequence<R, N, P>(g, b, acc.data());
+    put<R>(io->d_LR, acc.data(), P * P);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int elbo_fwd(const kvae_dims* d, const kvae_elbo_fwd* io) {
+    ElboFwdArgs<R> g = mk<R>(d, io);
+    for (int t = 0; t < d->T; ++t)
+        for (int b = 0; b < d->B; ++b) elbo_forward_pair<R, N, P>(g, t, b);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int elbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
+    using PG = ElboParamGrads<N, P>;
+    ElboBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.g_obs = (const R*)io->g_obs; g.g_trans = (const R*)io->g_trans;
+    g.g_post = (const R*)io->g_post;
+    g.d_a = (R*)io->d_a; g.d_ms = (R*)io->d_mean_smooth; g.d_Ps = (R*)io->d_cov_smooth;
+    g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs; g.partial = nullptr;
+    std::vector<R> acc(PG::LEN, R(0));
+    for (int t = 0; t < d->T; ++t)
+        for (int b = 0; b < d->B; ++b) elbo_backward_pair<R, N, P>(g, t, b, acc.data());
+    put<R>(io->d_Q, acc.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, acc.data() + PG::OFF_R, P * P);
+    put<R>(io->d_m0, acc.data() + PG::OFF_M0, N);
+    put<R>(io->d_P0, acc.data() + PG::OFF_P0, N * N);
+    return 0;
+}
+
+}  // namespace
+
+#define DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(8, 4, 4)
+#define CASE(n_, p_, K_)                                          \
+    if (d->n == n_ && d->p == p_ && d->K == K_) {                 \
+        if (d->dtype == KVAE_F32) return FN<float, n_, p_, K_>ARGS; \
+        return FN<double, n_, p_, K_>ARGS;                        \
+    }
+
+extern "C" {
+int hostsim_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io) {
+#define FN filter_fwd
+#define ARGS (d, io)
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io) {
+#define FN filter_bwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io) {
+#define FN smooth_fwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io) {
+#define FN smooth_bwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io) {
+#define FN elbo_fwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io) {
+#define FN elbo_bwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+}
