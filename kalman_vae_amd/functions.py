@@ -1,0 +1,243 @@
+"""torch.autograd.Function wrappers over the HIP kernels (C ABI in
+include/kvae_kalman.h).  PyTorch is used here for device memory, the current
+stream and the autograd graph only; all arithmetic of the three ops and of
+their backward passes runs in kalman_vae_amd/csrc/kernels.hip.
+
+Each Function mirrors one piece of the reference:
+  KalmanFilterFunction  - recursion of kvae/state_space_model.py:284-352
+  KalmanSmoothFunction  - kvae/state_space_model.py:375-484
+  KalmanElboFunction    - kvae/kalman_vae.py:191-242 (before `aggregate`)
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi as capi
+
+# A persistent int32 status word per device.  Kernels OR failure bits into it;
+# read_status() fetches and clears it (one host sync).
+_status_words = {}
+
+
+def status_word(device):
+    key = (device.type, device.index)
+    if key not in _status_words:
+        _status_words[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _status_words[key]
+
+
+def read_status(device, clear=True):
+    word = status_word(device)
+    value = int(word.item())
+    if clear and value:
+        word.zero_()
+    return value
+
+
+def raise_on_status(device):
+    value = read_status(device)
+    if value:
+        raise ValueError("Kalman kernels: " + capi.status_message(value))
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _dims(T, B, n, p, K, dtype, symmetrize, burn_in):
+    lib = capi.load()
+    code = capi.dtype_code(dtype)
+    if not lib.kvae_supported(n, p, K, code):
+        raise NotImplementedError(
+            f"no HIP kernel compiled for z_dim={n}, a_dim={p}, K={K}; add the "
+            "combination to KVAE_DIM_LIST in kalman_vae_amd/csrc/kernels.hip")
+    return capi.Dims(T, B, n, p, K, code, int(bool(symmetrize)), int(max(0, burn_in)))
+
+
+def _workspace(dims, op, device):
+    nbytes = capi.load().kvae_workspace_bytes(C.byref(dims), op)
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device), int(nbytes)
+
+
+def _any_K(n, p):
+    """The smoother and ELBO kernels do not depend on K, but kernels are keyed on
+    (n, p, K): use any K compiled for this (n, p)."""
+    lib = capi.load()
+    for K in range(1, 33):
+        if lib.kvae_supported(n, p, K, capi.KVAE_F32):
+            return K
+    raise NotImplementedError(f"no HIP kernel compiled for z_dim={n}, a_dim={p}")
+
+
+class KalmanFilterFunction(torch.autograd.Function):
+    """(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in) ->
+    (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs).
+
+    m_in/P_in of shape (n)/(n,n) start every sequence from the same state;
+    (B,n)/(B,n,n) continue a recursion (segment mode)."""
+
+    @staticmethod
+    def forward(ctx, a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize, burn_in, want_mats):
+        capi.require_gpu(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in)
+        a, alpha, mask, A_K, C_K, Q, R, m_in, P_in = map(
+            _c, (a, alpha, mask, A_K, C_K, Q, R, m_in, P_in))
+        T, B, p = a.shape
+        K, n = A_K.shape[0], A_K.shape[1]
+        if alpha.shape != (T + 1, B, K):
+            raise ValueError(f"alpha must have shape {(T + 1, B, K)}, got {tuple(alpha.shape)}")
+        dims = _dims(T, B, n, p, K, a.dtype, symmetrize, burn_in)
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+        As = new(T + 1, B, n, n) if want_mats else None
+        Cs = new(T + 1, B, p, n) if want_mats else None
+        io = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                       m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2),
+                       mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs,
+                       status=status_word(a.device))
+        capi.check(capi.load().kvae_filter_forward(C.byref(dims), C.byref(io),
+                                                   capi.current_stream_ptr()))
+        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn)
+        ctx.dims = dims
+        ctx.set_materialize_grads(False)
+        if not want_mats:
+            As, Cs = a.new_empty(0), a.new_empty(0)
+            ctx.mark_non_differentiable(As, Cs)
+        return m, P, mn, Pn, As, Cs
+
+    @staticmethod
+    def backward(ctx, g_m, g_P, g_mn, g_Pn, g_As, g_Cs):
+        a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn = ctx.saved_tensors
+        # contiguous copies must outlive the launch: keep them in locals
+        g_m, g_P, g_mn, g_Pn, g_As, g_Cs = map(_c, (g_m, g_P, g_mn, g_Pn, g_As, g_Cs))
+        dims = ctx.dims
+        T, B, n, p, K = dims.T, dims.B, dims.n, dims.p, dims.K
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        d_a, d_alpha = new(T, B, p), new(T + 1, B, K)
+        d_m_in, d_P_in = new(B, n), new(B, n, n)
+        d_A_K, d_C_K, d_Q, d_R = new(K, n, n), new(K, p, n), new(n, n), new(p, p)
+        io = capi.FilterBwd()
+        capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m_in=m_in,
+                  P_in=P_in, carry_per_sequence=int(m_in.dim() == 2), mean_filt=m, cov_filt=P,
+                  mean_pred=mn, cov_pred=Pn)
+        capi.fill(io, g_mean_filt=g_m, g_cov_filt=g_P, g_mean_pred=g_mn,
+                  g_cov_pred=g_Pn, g_mat_As=g_As, g_mat_Cs=g_Cs, d_a=d_a,
+                  d_alpha=d_alpha, d_m_in=d_m_in, d_P_in=d_P_in, d_A_K=d_A_K, d_C_K=d_C_K,
+                  d_Q=d_Q, d_R=d_R)
+        ws, nbytes = _workspace(dims, capi.OP_FILTER_BWD, a.device)
+        capi.check(capi.load().kvae_filter_backward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                    nbytes, capi.current_stream_ptr()))
+        if m_in.dim() == 1:
+            d_m_in = d_m_in.sum(0) if ctx.needs_input_grad[7] else None
+            d_P_in = d_P_in.sum(0) if ctx.needs_input_grad[8] else None
+        return d_a, d_alpha, None, d_A_K, d_C_K, d_Q, d_R, d_m_in, d_P_in, None, None, None
+
+
+class KalmanSmoothFunction(torch.autograd.Function):
+    """(mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs, LR, eps_state,
+    eps_obs) -> (mean_smooth, cov_smooth, zs, as_resampled)."""
+
+    @staticmethod
+    def forward(ctx, m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs, symmetrize, burn_in):
+        capi.require_gpu(m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs)
+        m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs = map(
+            _c, (m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs))
+        T, B, n = m.shape
+        p = Cs.shape[2]
+        dims = _dims(T, B, n, p, _any_K(n, p), m.dtype, symmetrize, burn_in)
+        new = lambda *s: torch.empty(s, dtype=m.dtype, device=m.device)
+        ms, Ps, zs, ares = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, p)
+        io = capi.fill(capi.SmoothFwd(), mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn,
+                       mat_As=As, mat_Cs=Cs, LR=LR, eps_state=eps_state, eps_obs=eps_obs,
+                       mean_smooth=ms, cov_smooth=Ps, zs=zs, as_resampled=ares,
+                       status=status_word(m.device))
+        capi.check(capi.load().kvae_smooth_forward(C.byref(dims), C.byref(io),
+                                                   capi.current_stream_ptr()))
+        ctx.save_for_backward(m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs, ms, Ps)
+        ctx.dims = dims
+        ctx.set_materialize_grads(False)
+        return ms, Ps, zs, ares
+
+    @staticmethod
+    def backward(ctx, g_ms, g_Ps, g_zs, g_ares):
+        m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs, ms, Ps = ctx.saved_tensors
+        g_ms, g_Ps, g_zs, g_ares = map(_c, (g_ms, g_Ps, g_zs, g_ares))  # kept alive past the launch
+        dims = ctx.dims
+        T, B, n, p = dims.T, dims.B, dims.n, dims.p
+        new = lambda *s: torch.empty(s, dtype=m.dtype, device=m.device)
+        d_m, d_P, d_mn, d_Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+        d_As, d_Cs = new(T + 1, B, n, n), new(T + 1, B, p, n)
+        want_LR = LR is not None and eps_obs is not None and ctx.needs_input_grad[6]
+        d_LR = new(p, p) if want_LR else None
+        io = capi.SmoothBwd()
+        capi.fill(io.fwd, mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As,
+                  mat_Cs=Cs, LR=LR, eps_state=eps_state, eps_obs=eps_obs, mean_smooth=ms,
+                  cov_smooth=Ps)
+        capi.fill(io, g_mean_smooth=g_ms, g_cov_smooth=g_Ps, g_zs=g_zs,
+                  g_as_resampled=g_ares, d_mean_filt=d_m, d_cov_filt=d_P, d_mean_pred=d_mn,
+                  d_cov_pred=d_Pn, d_mat_As=d_As, d_mat_Cs=d_Cs, d_LR=d_LR)
+        ws, nbytes = _workspace(dims, capi.OP_SMOOTH_BWD, m.device)
+        capi.check(capi.load().kvae_smooth_backward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                    nbytes, capi.current_stream_ptr()))
+        return d_m, d_P, d_mn, d_Pn, d_As, d_Cs, d_LR, None, None, None, None
+
+
+class KalmanElboFunction(torch.autograd.Function):
+    """(a, mean_smooth, cov_smooth, mat_As, mat_Cs, Q, R, m0, P0, eps) ->
+    (obs, trans, post) each (T,B), and the sample z (T,B,n)."""
+
+    @staticmethod
+    def forward(ctx, a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
+        capi.require_gpu(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+        a, ms, Ps, As, Cs, Q, R, m0, P0, eps = map(_c, (a, ms, Ps, As, Cs, Q, R, m0, P0, eps))
+        T, B, n = ms.shape
+        p = a.shape[2]
+        dims = _dims(T, B, n, p, _any_K(n, p), a.dtype, True, 0)
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        obs, trans, post, z = new(T, B), new(T, B), new(T, B), new(T, B, n)
+        io = capi.fill(capi.ElboFwd(), a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs,
+                       Q=Q, R=R, m0=m0, P0=P0, eps=eps, obs=obs, trans=trans, post=post, z=z,
+                       status=status_word(a.device))
+        capi.check(capi.load().kvae_elbo_forward(C.byref(dims), C.byref(io),
+                                                 capi.current_stream_ptr()))
+        ctx.save_for_backward(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+        ctx.dims = dims
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(z)
+        return obs, trans, post, z
+
+    @staticmethod
+    def backward(ctx, g_obs, g_trans, g_post, _g_z):
+        a, ms, Ps, As, Cs, Q, R, m0, P0, eps = ctx.saved_tensors
+        g_obs, g_trans, g_post = map(_c, (g_obs, g_trans, g_post))  # kept alive past the launch
+        dims = ctx.dims
+        T, B, n, p = dims.T, dims.B, dims.n, dims.p
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        d_a, d_ms, d_Ps = new(T, B, p), new(T, B, n), new(T, B, n, n)
+        d_As, d_Cs = new(T + 1, B, n, n), new(T + 1, B, p, n)
+        d_Q, d_R, d_m0, d_P0 = new(n, n), new(p, p), new(n), new(n, n)
+        io = capi.ElboBwd()
+        capi.fill(io.fwd, a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs, Q=Q, R=R,
+                  m0=m0, P0=P0, eps=eps)
+        capi.fill(io, g_obs=g_obs, g_trans=g_trans, g_post=g_post, d_a=d_a,
+                  d_mean_smooth=d_ms, d_cov_smooth=d_Ps, d_mat_As=d_As, d_mat_Cs=d_Cs, d_Q=d_Q,
+                  d_R=d_R, d_m0=d_m0, d_P0=d_P0)
+        ws, nbytes = _workspace(dims, capi.OP_ELBO_BWD, a.device)
+        capi.check(capi.load().kvae_elbo_backward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                  nbytes, capi.current_stream_ptr()))
+        return d_a, d_ms, d_Ps, d_As, d_Cs, d_Q, d_R, d_m0, d_P0, None
+
+
+def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,
+                        want_mats=True):
+    return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,
+                                      burn_in, want_mats)
+
+
+def kalman_smooth_steps(m, P, mn, Pn, As, Cs, LR=None, eps_state=None, eps_obs=None,
+                        symmetrize=True, burn_in=0):
+    return KalmanSmoothFunction.apply(m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs, symmetrize,
+                                      burn_in)
+
+
+def kalman_elbo_terms(a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
+    return KalmanElboFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)

@@ -1,0 +1,279 @@
+"""Drop-in for the reference's ``StateSpaceModel`` whose filter and smoother run
+as HIP kernels on MI355X.
+
+Same constructor arguments, parameter names (``a_0, _mat_A_K, _mat_C_K,
+_mat_Q_L, _mat_R_L, weight_model.*`` -- reference checkpoints load), matrix
+properties/setters and the same ``kalman_filter`` / ``kalman_smooth``
+signatures and return tuples as kvae/state_space_model.py:15-484.
+
+How the work is split:
+  * The dynamics-parameter network stays a PyTorch module.  Without an
+    observation mask its inputs are the observations themselves, so all mixing
+    weights are produced by ONE network call over the whole sequence and the
+    T-step recursion runs inside a single kernel launch.
+  * With a mask the network input at step t depends on the filter state
+    (state_space_model.py:232-282), so the recursion is cut into one-step
+    kernel segments with the imputation and the network call in between.
+  * Random draws are made with the same primitive and in the same order as
+    the reference's ``MultivariateNormal.rsample`` calls, so a seeded run
+    consumes the generator identically (``rng_parity``; switch it off to draw
+    one tensor per call instead of two per step).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch.distributions.utils import _standard_normal
+
+from . import functions as F
+from .dynamics_parameter_network import make_weight_model
+from .misc import _validate_shape
+from .sample_control import SampleControl, wants_noise
+
+
+class StateSpaceModel(nn.Module):
+    def __init__(
+        self,
+        a_dim: int,
+        z_dim: int,
+        K: int,
+        dynamics_parameter_network: str,
+        hidden_dim: int = 128,
+        num_layers: int = 2,
+        Q_reg: float = 1e-3,
+        R_reg: float = 1e-3,
+        init_transition_reg_weight: float = 0.9,
+        init_observation_reg_weight: float = 0.9,
+        initial_state_mean: Optional[torch.Tensor] = None,
+        initial_state_covariance: Optional[torch.Tensor] = None,
+        fix_matrices: bool = False,
+        learn_noise_covariance: bool = False,
+        init_noise_scale: float = 1.0,
+    ):
+        super().__init__()
+        self.a_dim, self.z_dim, self.K = a_dim, z_dim, K
+        self.a_0 = nn.Parameter(torch.zeros(a_dim))
+        wa, wc = init_transition_reg_weight, init_observation_reg_weight
+        self._mat_A_K = nn.Parameter((1.0 - wa) * torch.randn(K, z_dim, z_dim)
+                                     + wa * torch.eye(z_dim))
+        self._mat_C_K = nn.Parameter((1.0 - wc) * torch.randn(K, a_dim, z_dim)
+                                     + wc * torch.eye(a_dim, z_dim))
+        # the *unconstrained* square factors are the parameters; Q = L L^T + reg I
+        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(z_dim)))
+        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(a_dim)))
+        self.learn_noise_covariance = learn_noise_covariance
+        self.fix_matrices = fix_matrices
+        self.Q_reg, self.R_reg = Q_reg, R_reg
+        # plain tensors (not buffers: they must stay out of the state_dict)
+        self._a_eye = torch.eye(a_dim)
+        self._z_eye = torch.eye(z_dim)
+        if initial_state_mean is None:
+            initial_state_mean = torch.zeros(z_dim)
+        else:
+            _validate_shape(initial_state_mean, (z_dim,), "initial_state_mean")
+        if initial_state_covariance is None:
+            initial_state_covariance = torch.eye(z_dim)
+        else:
+            _validate_shape(initial_state_covariance, (z_dim, z_dim), "initial_state_covariance")
+        self.initial_state_mean = initial_state_mean
+        self.initial_state_covariance = initial_state_covariance
+        self.weight_model = make_weight_model(dynamics_parameter_network, a_dim, K,
+                                              hidden_dim, num_layers)
+        # behaviour switches that have no counterpart in the reference
+        self.rng_parity = True      # draw noise exactly like the reference does
+        self.check_numerics = True  # raise on a non-positive-definite covariance (host sync)
+
+    def _apply(self, fn):
+        super()._apply(fn)
+        for name in ("_a_eye", "_z_eye", "initial_state_mean", "initial_state_covariance"):
+            setattr(self, name, fn(getattr(self, name)))
+        return self
+
+    # -- matrices (state_space_model.py:112-170) ------------------------------
+    def _gated(self, matrix, noise):
+        if self.fix_matrices or (noise and not self.learn_noise_covariance):
+            matrix = matrix.detach()
+        return matrix
+
+    @property
+    def mat_Q(self):
+        return self._gated(self._mat_Q_L @ self._mat_Q_L.T + self._z_eye * self.Q_reg, True)
+
+    @property
+    def mat_R(self):
+        return self._gated(self._mat_R_L @ self._mat_R_L.T + self._a_eye * self.R_reg, True)
+
+    @property
+    def mat_A_K(self):
+        return self._gated(self._mat_A_K, False)
+
+    @property
+    def mat_C_K(self):
+        return self._gated(self._mat_C_K, False)
+
+    @mat_Q.setter
+    def mat_Q(self, value):
+        _validate_shape(value, (self.z_dim, self.z_dim), "mat_Q")
+        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(value))
+        self.Q_reg = 0.0
+
+    @mat_R.setter
+    def mat_R(self, value):
+        _validate_shape(value, (self.a_dim, self.a_dim), "mat_R")
+        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(value))
+        self.R_reg = 0.0
+
+    @mat_A_K.setter
+    def mat_A_K(self, value):
+        _validate_shape(value, (self.K, self.z_dim, self.z_dim), "mat_A_K")
+        self._mat_A_K = nn.Parameter(value)
+
+    @mat_C_K.setter
+    def mat_C_K(self, value):
+        _validate_shape(value, (self.K, self.a_dim, self.z_dim), "mat_C_K")
+        self._mat_C_K = nn.Parameter(value)
+
+    # -- helpers --------------------------------------------------------------
+    def _modes(self, sample_control, filtering):
+        state = wants_noise(sample_control.state_transition, "state_transition")
+        obs = wants_noise(sample_control.observation, "observation")
+        if filtering and self.training:
+            # "mean" is an evaluation-only mode of the filter (:237-240, :256-259)
+            if not state:
+                raise ValueError("sample_control.state_transition must be 'sample' for training")
+            if not obs:
+                raise ValueError("sample_control.observation must be 'sample' for training")
+        return state, obs
+
+    @staticmethod
+    def _draw(shape, like):
+        return _standard_normal(shape, dtype=like.dtype, device=like.device)
+
+    def _finish(self, device):
+        if self.check_numerics:
+            F.raise_on_status(device)
+
+    # -- filter (state_space_model.py:172-373) ---------------------------------
+    def kalman_filter(
+        self,
+        as_: torch.Tensor,
+        sample_control: SampleControl,
+        observation_mask: Optional[torch.Tensor] = None,
+        learn_weight_model: bool = True,
+        symmetrize_covariance: bool = True,
+        burn_in: int = 0,
+    ):
+        T, B = as_.shape[:2]
+        state_noise, obs_noise = self._modes(sample_control, filtering=True)
+        self.weight_model.clear_hidden_state()
+        if observation_mask is None:
+            out = self._filter_unmasked(as_, state_noise, obs_noise, learn_weight_model,
+                                        symmetrize_covariance, burn_in)
+        else:
+            out = self._filter_masked(as_, observation_mask.to(as_.dtype), state_noise, obs_noise,
+                                      learn_weight_model, symmetrize_covariance, burn_in)
+        self._finish(as_.device)
+        return out
+
+    def _filter_unmasked(self, as_, state_noise, obs_noise, learn_weight_model, symmetrize, burn_in):
+        T, B = as_.shape[:2]
+        if self.rng_parity:
+            # the reference draws the imputation noise every step although its
+            # result is unused without a mask; consume the generator alike
+            for _ in range(T):
+                if state_noise:
+                    self._draw((B, self.z_dim), as_)
+                if obs_noise:
+                    self._draw((B, self.a_dim), as_)
+        later = self.weight_model(as_)  # rows 1..T: weights after seeing a_0..a_{T-1}
+        if not learn_weight_model:
+            later = later.detach()
+        first = torch.full((1, B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
+        alpha = torch.cat([first, later], dim=0)
+        m, P, mn, Pn, As, Cs = F.kalman_filter_steps(
+            as_, alpha, None, self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R,
+            self.initial_state_mean, self.initial_state_covariance,
+            symmetrize=symmetrize, burn_in=burn_in)
+        return m, P, mn, Pn, As, Cs, as_, alpha[:T]
+
+    def _filter_masked(self, as_, mask, state_noise, obs_noise, learn_weight_model, symmetrize,
+                       burn_in):
+        T, B = as_.shape[:2]
+        A_K, C_K, Q, R = self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R
+        L_Q = torch.linalg.cholesky(Q) if state_noise else None
+        L_R = torch.linalg.cholesky(R) if obs_noise else None
+        mix = lambda w, bases: torch.einsum("bk,kij->bij", w, bases)
+        w = torch.full((B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
+        m_pred = self.initial_state_mean.expand(B, -1).contiguous()
+        P_pred = self.initial_state_covariance.expand(B, -1, -1).contiguous()
+        A_t = mix(w, A_K)
+        out = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C", "aw", "w")}
+        for t in range(T):
+            C_t = mix(w, C_K)
+            # imputation (:232-277); m_pred already is the one-step prediction
+            z_imp = torch.bmm(A_t, m_pred.unsqueeze(-1)).squeeze(-1)
+            if state_noise:
+                z_imp = z_imp + self._draw((B, self.z_dim), as_) @ L_Q.T
+            a_imp = torch.bmm(C_t, z_imp.unsqueeze(-1)).squeeze(-1)
+            if obs_noise:
+                a_imp = a_imp + self._draw((B, self.a_dim), as_) @ L_R.T
+            mu = mask[t].unsqueeze(-1)
+            a_w = mu * as_[t] + (1.0 - mu) * a_imp
+            w_next = self.weight_model(a_w.unsqueeze(0)).squeeze(0)
+            if not learn_weight_model:
+                w_next = w_next.detach()
+            A_next = mix(w_next, A_K)
+            m, P, mn, Pn, _, _ = F.kalman_filter_steps(
+                as_[t:t + 1], torch.stack([w, w_next]), mask[t:t + 1], A_K, C_K, Q, R,
+                m_pred, P_pred, symmetrize=symmetrize, burn_in=1 if t < burn_in else 0,
+                want_mats=False)
+            m_pred, P_pred = mn[0], Pn[0]
+            for k, v in zip(("m", "P", "mn", "Pn", "A", "C", "aw", "w"),
+                            (m[0], P[0], m_pred, P_pred, A_t, C_t, a_w, w)):
+                out[k].append(v)
+            w, A_t = w_next, A_next
+        out["A"].append(A_t)
+        out["C"].append(mix(w, C_K))
+        st = {k: torch.stack(v) for k, v in out.items()}
+        return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
+
+    # -- smoother (state_space_model.py:375-484) --------------------------------
+    def kalman_smooth(
+        self,
+        as_: torch.Tensor,
+        filter_means: torch.Tensor,
+        filter_covariances: torch.Tensor,
+        filter_next_means: torch.Tensor,
+        filter_next_covariances: torch.Tensor,
+        mat_As: torch.Tensor,
+        mat_Cs: torch.Tensor,
+        sample_control: SampleControl,
+        symmetrize_covariance: bool = True,
+        burn_in: int = 0,
+    ):
+        T, B, _ = as_.shape
+        state_noise, obs_noise = self._modes(sample_control, filtering=False)
+        eps_state = eps_obs = L_R = None
+        if self.rng_parity and (state_noise or obs_noise):
+            # draw order of the reference: t = T-1 .. 0, state then observation
+            es, eo = [None] * T, [None] * T
+            for t in reversed(range(T)):
+                if state_noise:
+                    es[t] = self._draw((B, self.z_dim), as_)
+                if obs_noise:
+                    eo[t] = self._draw((B, self.a_dim), as_)
+            eps_state = torch.stack(es) if state_noise else None
+            eps_obs = torch.stack(eo) if obs_noise else None
+        else:
+            if state_noise:
+                eps_state = self._draw((T, B, self.z_dim), as_)
+            if obs_noise:
+                eps_obs = self._draw((T, B, self.a_dim), as_)
+        if obs_noise:
+            L_R = torch.linalg.cholesky(self.mat_R)
+        out = F.kalman_smooth_steps(
+            filter_means, filter_covariances, filter_next_means, filter_next_covariances,
+            mat_As, mat_Cs, LR=L_R, eps_state=eps_state, eps_obs=eps_obs,
+            symmetrize=symmetrize_covariance, burn_in=burn_in)
+        self._finish(as_.device)
+        return out

@@ -1,0 +1,146 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol,
+the ctypes mirrors match the C structs, and the host logic around the kernels
+(weight networks, parameter properties, state_dict layout, aggregation,
+error behaviour) matches the reference as recorded in the golden fixtures.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+from golden_util import Golden, golden_names, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kvae_kalman.h")
+
+
+def test_library_exports_every_declared_symbol():
+    from kalman_vae_amd import _capi as capi
+    declared = set(re.findall(r"\b(kvae_[a-z_]+)\s*\(", open(HEADER).read()))
+    assert declared == set(capi.EXPORTS)
+    lib = C.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_host_only_entry_points():
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    assert lib.kvae_version() == 1
+    assert lib.kvae_supported(4, 2, 3, capi.KVAE_F32) == 1
+    assert lib.kvae_supported(4, 2, 3, capi.KVAE_F64) == 1
+    assert lib.kvae_supported(5, 2, 3, capi.KVAE_F32) == 0
+    assert lib.kvae_supported(4, 2, 3, 7) == 0
+    d = capi.Dims(20, 4096, 4, 2, 3, capi.KVAE_F32, 1, 0)
+    rows = 4096 // 64
+    assert lib.kvae_workspace_bytes(C.byref(d), capi.OP_FILTER_BWD) == rows * (48 + 24 + 16 + 4) * 4
+    assert lib.kvae_workspace_bytes(C.byref(d), capi.OP_SMOOTH_BWD) == rows * 4 * 4
+    assert lib.kvae_workspace_bytes(C.byref(d), 99) == 0
+    assert b"workspace" in lib.kvae_error_string(-3)
+    # argument validation happens before any launch
+    io = capi.FilterFwd()
+    assert lib.kvae_filter_forward(C.byref(d), C.byref(io), None) == -1
+    bad = capi.Dims(0, 4, 4, 2, 3, 0, 1, 0)
+    assert lib.kvae_filter_forward(C.byref(bad), C.byref(io), None) == -1
+
+
+def test_ctypes_structs_match_header():
+    from kalman_vae_amd import _capi as capi
+    names = {"kvae_dims": capi.Dims, "kvae_filter_fwd": capi.FilterFwd,
+             "kvae_filter_bwd": capi.FilterBwd, "kvae_smooth_fwd": capi.SmoothFwd,
+             "kvae_smooth_bwd": capi.SmoothBwd, "kvae_elbo_fwd": capi.ElboFwd,
+             "kvae_elbo_bwd": capi.ElboBwd}
+    src = '#include <stdio.h>\n#include "kvae_kalman.h"\nint main(void){\n'
+    for n in names:
+        src += f'printf("{n} %zu\\n", sizeof({n}));\n'
+    src += 'printf("off_status %zu\\n", offsetof(kvae_filter_fwd, status));\n'
+    src += 'printf("off_dLR %zu\\n", offsetof(kvae_smooth_bwd, d_LR));\n'
+    src += 'printf("off_dP0 %zu\\n", offsetof(kvae_elbo_bwd, d_P0));\nreturn 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "s.c")
+        open(cfile, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
+        out = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for n, cls in names.items():
+        assert int(out[n]) == C.sizeof(cls), n
+    assert int(out["off_status"]) == capi.FilterFwd.status.offset
+    assert int(out["off_dLR"]) == capi.SmoothBwd.d_LR.offset
+    assert int(out["off_dP0"]) == capi.ElboBwd.d_P0.offset
+
+
+def test_no_cpu_path():
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    ssm = StateSpaceModel(2, 4, 3, "mlp").eval()
+    a = torch.randn(5, 3, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ssm.kalman_filter(a, SampleControl(state_transition="mean", observation="mean"))
+
+
+@pytest.mark.parametrize("name", golden_names("g*"))
+def test_state_dict_and_weight_network_match_reference(name):
+    """Reference checkpoints load key for key, and the weight network fed with
+    the reference's network inputs reproduces the reference's mixing weights."""
+    from kalman_vae_amd import StateSpaceModel
+    g = Golden(name)
+    c = g.cfg
+    ssm = StateSpaceModel(a_dim=c["p"], z_dim=c["n"], K=c["K"],
+                          dynamics_parameter_network=c["net"],
+                          hidden_dim=c.get("hidden_dim", 8), num_layers=c.get("num_layers", 2),
+                          Q_reg=float(g["in.Q_reg"]), R_reg=float(g["in.R_reg"])).to(g.dtype)
+    sd = {k[3:]: v for k, v in g.t.items() if k.startswith("sd.")}
+    assert set(sd) == set(ssm.state_dict())
+    ssm.load_state_dict(sd)
+    tol = 1e-12 if g.dtype == torch.float64 else 1e-5
+    assert rel_err(ssm.mat_Q, g["in.Q"]) < tol
+    assert rel_err(ssm.mat_R, g["in.R"]) < tol
+    # one call over the whole sequence == the reference's step-by-step calls
+    ssm.weight_model.clear_hidden_state()
+    w = ssm.weight_model(g["out.filter_as"])
+    got = torch.cat([torch.full_like(w[:1], 1.0 / c["K"]), w[:-1]])
+    assert rel_err(got, g["out.weights"]) < (1e-10 if g.dtype == torch.float64 else 1e-5)
+
+
+def test_matrix_properties_gates_and_setters():
+    from kalman_vae_amd import StateSpaceModel
+    ssm = StateSpaceModel(2, 4, 3, "mlp")
+    assert not ssm.mat_Q.requires_grad and not ssm.mat_R.requires_grad
+    assert ssm.mat_A_K.requires_grad and ssm.mat_C_K.requires_grad
+    assert torch.allclose(ssm.mat_Q, 1.001 * torch.eye(4))
+    ssm.learn_noise_covariance = True
+    assert ssm.mat_Q.requires_grad
+    ssm.fix_matrices = True
+    assert not ssm.mat_Q.requires_grad and not ssm.mat_A_K.requires_grad
+    ssm.mat_Q = 2.0 * torch.eye(4)
+    assert ssm.Q_reg == 0.0 and torch.allclose(ssm.mat_Q, 2.0 * torch.eye(4))
+    with pytest.raises(ValueError):
+        ssm.mat_R = torch.eye(3)
+    with pytest.raises(ValueError):
+        StateSpaceModel(2, 4, 3, "mlp", initial_state_mean=torch.zeros(3))
+    # eye/initial-state tensors follow .to() but stay out of the state_dict
+    ssm = ssm.double()
+    assert ssm._z_eye.dtype == torch.float64
+    assert ssm.initial_state_covariance.dtype == torch.float64
+    assert "initial_state_mean" not in ssm.state_dict()
+
+
+def test_aggregate_and_sample_control():
+    from kalman_vae_amd import SampleControl, aggregate
+    from kalman_vae_amd.misc import aggregate_weights
+    v = torch.arange(12.0).reshape(3, 4)
+    for so in ("mean", "sum"):
+        for bo in ("mean", "sum"):
+            want = getattr(getattr(v, so)(0), bo)(0)
+            assert torch.allclose(aggregate(v, 3, 4, so, bo), want)
+            assert abs(aggregate_weights(3, 4, so, bo) * float(v.sum()) - float(want)) < 1e-9
+    with pytest.raises(ValueError):
+        aggregate(v, 4, 3, "mean", "mean")
+    with pytest.raises(ValueError):
+        aggregate(v, 3, 4, "max", "mean")
+    sc = SampleControl()
+    assert (sc.encoder, sc.decoder, sc.state_transition, sc.observation) == (
+        "sample", "mean", "sample", "sample")
