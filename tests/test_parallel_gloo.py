@@ -1,0 +1,72 @@
+"""World-size-2 CPU test (gloo) of the data-parallel path: each rank takes its
+shard of the batch, computes gradients of the Kalman objective for the shard
+(with the oracle as the compute here -- the package has no CPU kernels), and
+the flat-bucket all-reduce must reproduce the full-batch gradients."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kalman_vae_amd.parallel import FlatGradBucket, shard_batch, shard_bounds
+
+
+def test_shard_bounds_cover_everything():
+    for total in (1, 7, 64, 1000):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_bounds(total, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
+                assert e0 == b1
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _objective(model, a, eps):
+    from oracle import kalman_oracle as O
+    model.weight_model.clear_hidden_state()
+    obj, _ = O.kalman_objective(
+        a, model._mat_A_K, model._mat_C_K, model.mat_Q, model.mat_R, model.initial_state_mean,
+        model.initial_state_covariance, model.weight_model, eps,
+        sequence_operation="mean", batch_operation="sum")
+    return obj
+
+
+def _make(seed=0):
+    from kalman_vae_amd import StateSpaceModel
+    torch.manual_seed(seed)
+    model = StateSpaceModel(2, 4, 3, "lstm", hidden_dim=8).double()
+    a = 0.7 * torch.randn(6, 10, 2, dtype=torch.float64)
+    eps = torch.randn(6, 10, 4, dtype=torch.float64)
+    return model, a, eps
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, a, eps = _make()
+    a_r, eps_r = shard_batch(a, world, rank), shard_batch(eps, world, rank)
+    _objective(model, a_r, eps_r).backward()
+    bucket = FlatGradBucket(model.parameters())
+    flat = bucket.all_reduce(average=False)
+    if rank == 0:
+        torch.save(flat.clone(), out)
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_matches_full_batch(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "flat.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    model, a, eps = _make()
+    _objective(model, a, eps).backward()
+    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in model.parameters() if p.requires_grad])
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 1e-10 * max(1.0, float(want.abs().max()))
