@@ -1,0 +1,24 @@
+// Entry points of the wavefront-per-sequence translation unit
+// (wave_kernels.hip), called by the C ABI when no lane-per-sequence kernel is
+// compiled for the requested (n, p, K).  Same contracts as the kvae_* functions
+// of include/kvae_kalman.h; KVAE_E_UNSUPPORTED when (n, p, K, dtype) is not in
+// the wave list either.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/kvae_kalman.h"
+
+namespace kvae {
+int wave_supported(int n, int p, int K, int dtype);
+size_t wave_workspace_bytes(const kvae_dims* d, int op);
+int wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s);
+int wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws, size_t ws_bytes,
+                         hipStream_t s);
+int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s);
+int wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
+                         hipStream_t s);
+int wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s);
+int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
+                       hipStream_t s);
+}  // namespace kvae

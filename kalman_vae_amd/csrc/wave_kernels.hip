@@ -1,0 +1,226 @@
+// gfx950 kernels of the wavefront-per-sequence variant (kalman_wave.h): one
+// 64-thread workgroup per sequence, all matrices of the sequence in LDS.
+// Used for state dimensions too large for the lane-per-sequence kernels
+// (z_dim = 32: a covariance is 4 KiB, the filter's working set ~30 KiB).
+//
+// Grid = B workgroups.  Parameter-gradient sums are kept in registers
+// (distributed over the lanes), written as one row per sequence and summed by
+// reduce_rows_kernel in a fixed order (no float atomics).
+#include "wave_api.h"
+
+#include "kalman_wave.h"
+#include "launch_common.h"
+
+namespace kvae {
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(64) wave_filter_forward_kernel(FilterFwdArgs<R> g) {
+    __shared__ wave::FilterScratch<R, N, P, K> s;
+    wave::filter_forward_sequence<R, N, P, K>(g, blockIdx.x, s);
+}
+
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(64) wave_filter_backward_kernel(FilterBwdArgs<R> g) {
+    __shared__ wave::FilterBwdScratch<R, N, P, K> s;
+    wave::FilterGradAcc<R, N, P, K> acc;
+    acc.zero();
+    wave::filter_backward_sequence<R, N, P, K>(g, blockIdx.x, s, acc);
+    acc.store(g.partial + (long)blockIdx.x * FilterParamGrads<N, P, K>::LEN);
+}
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(64) wave_smooth_forward_kernel(SmoothFwdArgs<R> g) {
+    __shared__ wave::SmoothScratch<R, N, P> s;
+    wave::smooth_forward_sequence<R, N, P>(g, blockIdx.x, s);
+}
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(64) wave_smooth_backward_kernel(SmoothBwdArgs<R> g) {
+    __shared__ wave::SmoothBwdScratch<R, N, P> s;
+    wave::Acc<R, P * P> acc;
+    acc.zero();
+    wave::smooth_backward_sequence<R, N, P>(g, blockIdx.x, s, acc);
+    if (g.partial) acc.store(g.partial + (long)blockIdx.x * (P * P));
+}
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(64) wave_elbo_forward_kernel(ElboFwdArgs<R> g) {
+    __shared__ wave::ElboScratch<R, N, P> s;
+    wave::elbo_forward_sequence<R, N, P>(g, blockIdx.x, s);
+}
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(64) wave_elbo_backward_kernel(ElboBwdArgs<R> g) {
+    __shared__ wave::ElboBwdScratch<R, N, P> s;
+    wave::ElboGradAcc<R, N, P> acc;
+    acc.zero();
+    wave::elbo_backward_sequence<R, N, P>(g, blockIdx.x, s, acc);
+    acc.store(g.partial + (long)blockIdx.x * ElboParamGrads<N, P>::LEN);
+}
+
+// ---- launchers ---------------------------------------------------------------
+template <typename R, int N, int P, int K>
+int run_wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
+    if constexpr (sizeof(wave::FilterScratch<R, N, P, K>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        FilterFwdArgs<R> g = make_args<R>(d, io);
+        hipLaunchKernelGGL((wave_filter_forward_kernel<R, N, P, K>), dim3(d->B), dim3(64), 0, s, g);
+        return launch_status();
+    }
+}
+
+template <typename R, int N, int P, int K>
+int run_wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws,
+                             size_t ws_bytes, hipStream_t s) {
+    if constexpr (sizeof(wave::FilterBwdScratch<R, N, P, K>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        using PG = FilterParamGrads<N, P, K>;
+        if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
+        FilterBwdArgs<R> g = make_args<R>(d, io, ws);
+        hipLaunchKernelGGL((wave_filter_backward_kernel<R, N, P, K>), dim3(d->B), dim3(64), 0, s, g);
+        reduce_filter_grads<R, N, P, K>(io, ws, d->B, s);
+        return launch_status();
+    }
+}
+
+template <typename R, int N, int P>
+int run_wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
+    if constexpr (sizeof(wave::SmoothScratch<R, N, P>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        SmoothFwdArgs<R> g = make_args<R>(d, io);
+        hipLaunchKernelGGL((wave_smooth_forward_kernel<R, N, P>), dim3(d->B), dim3(64), 0, s, g);
+        return launch_status();
+    }
+}
+
+template <typename R, int N, int P>
+int run_wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws,
+                             size_t ws_bytes, hipStream_t s) {
+    if constexpr (sizeof(wave::SmoothBwdScratch<R, N, P>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        if (io->d_LR && ws_bytes < (size_t)d->B * P * P * sizeof(R)) return KVAE_E_WORKSPACE;
+        SmoothBwdArgs<R> g = make_args<R>(d, io, ws);
+        hipLaunchKernelGGL((wave_smooth_backward_kernel<R, N, P>), dim3(d->B), dim3(64), 0, s, g);
+        if (io->d_LR) reduce_smooth_grads<R, P>(io, ws, d->B, s);
+        return launch_status();
+    }
+}
+
+template <typename R, int N, int P>
+int run_wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
+    if constexpr (sizeof(wave::ElboScratch<R, N, P>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        ElboFwdArgs<R> g = make_args<R>(d, io);
+        hipLaunchKernelGGL((wave_elbo_forward_kernel<R, N, P>), dim3(d->B), dim3(64), 0, s, g);
+        return launch_status();
+    }
+}
+
+template <typename R, int N, int P>
+int run_wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+    if constexpr (sizeof(wave::ElboBwdScratch<R, N, P>) > LDS_LIMIT) {
+        return KVAE_E_UNSUPPORTED;
+    } else {
+        using PG = ElboParamGrads<N, P>;
+        if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
+        ElboBwdArgs<R> g = make_args<R>(d, io, ws);
+        hipLaunchKernelGGL((wave_elbo_backward_kernel<R, N, P>), dim3(d->B), dim3(64), 0, s, g);
+        reduce_elbo_grads<R, N, P>(io, ws, d->B, s);
+        return launch_status();
+    }
+}
+
+// (n, p, K) compiled for the wavefront-per-sequence path
+#define KVAE_WAVE_DIM_LIST(X) \
+    X(32, 16, 8)              \
+    X(16, 8, 4)               \
+    X(6, 3, 2)
+
+// all six scratch structs of a combination must fit the LDS for it to be usable
+template <typename R, int N, int P, int K>
+constexpr bool wave_fits() {
+    return sizeof(wave::FilterBwdScratch<R, N, P, K>) <= LDS_LIMIT &&
+           sizeof(wave::SmoothBwdScratch<R, N, P>) <= LDS_LIMIT &&
+           sizeof(wave::ElboBwdScratch<R, N, P>) <= LDS_LIMIT;
+}
+
+#define KVAE_WAVE_CASE(n_, p_, K_)                                     \
+    if (d->n == n_ && d->p == p_ && d->K == K_) {                      \
+        if (d->dtype == KVAE_F32) return KVAE_CALL(float, n_, p_, K_); \
+        return KVAE_CALL(double, n_, p_, K_);                          \
+    }
+
+int wave_supported(int n, int p, int K, int dtype) {
+#define KVAE_SUP(n_, p_, K_)                                                        \
+    if (n == n_ && p == p_ && K == K_)                                              \
+        return dtype == KVAE_F32 ? wave_fits<float, n_, p_, K_>()                   \
+                                 : (dtype == KVAE_F64 ? wave_fits<double, n_, p_, K_>() : 0);
+    KVAE_WAVE_DIM_LIST(KVAE_SUP)
+#undef KVAE_SUP
+    return 0;
+}
+
+size_t wave_workspace_bytes(const kvae_dims* d, int op) {
+    const size_t el = d->dtype == KVAE_F32 ? 4 : 8;
+    const long n = d->n, p = d->p, K = d->K;
+    switch (op) {
+        case KVAE_OP_FILTER_BWD:
+            return (size_t)d->B * (K * n * n + K * p * n + n * n + p * p) * el;
+        case KVAE_OP_SMOOTH_BWD:
+            return (size_t)d->B * (p * p) * el;
+        case KVAE_OP_ELBO_BWD:
+            return (size_t)d->B * (n * n + p * p + n + n * n) * el;
+        default:
+            return 0;
+    }
+}
+
+int wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_filter_forward<R, n_, p_, K_>(d, io, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+int wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_filter_backward<R, n_, p_, K_>(d, io, ws, ws_bytes, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_forward<R, n_, p_>(d, io, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+int wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_backward<R, n_, p_>(d, io, ws, ws_bytes, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+int wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_elbo_forward<R, n_, p_>(d, io, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+#define KVAE_CALL(R, n_, p_, K_) run_wave_elbo_backward<R, n_, p_>(d, io, ws, ws_bytes, s)
+    KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
+#undef KVAE_CALL
+    return KVAE_E_UNSUPPORTED;
+}
+
+}  // namespace kvae

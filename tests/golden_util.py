@@ -22,6 +22,10 @@ class Golden:
         self.cfg = json.loads(str(z["config"]))
         self.dtype = torch.float64 if self.cfg["dtype"] == "float64" else torch.float32
         self.t = {k: torch.from_numpy(np.array(z[k])) for k in z.files if k != "config"}
+        # "store_f32" fixtures were computed in float64 and stored in float32
+        self.stored_f32 = bool(self.cfg.get("store_f32", False))
+        self.t = {k: (v.to(self.dtype) if v.is_floating_point() else v)
+                  for k, v in self.t.items()}
 
     def __getitem__(self, key):
         return self.t[key]

@@ -13,6 +13,8 @@
 
 #include "../../include/kvae_kalman.h"
 #include "../../kalman_vae_amd/csrc/kalman_core.h"
+#include "../../kalman_vae_amd/csrc/kalman_wave.h"
+#include <memory>
 
 using namespace kvae;
 
@@ -134,6 +136,113 @@ int elbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
 
 }  // namespace
 
+
+// ---- wavefront-per-sequence source (kalman_wave.h) run by one host thread ----
+namespace {
+template <typename R>
+FilterBwdArgs<R> mkb(const kvae_dims* d, const kvae_filter_bwd* io) {
+    FilterBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_m = (const R*)io->g_mean_filt; g.g_P = (const R*)io->g_cov_filt;
+    g.g_mn = (const R*)io->g_mean_pred; g.g_Pn = (const R*)io->g_cov_pred;
+    g.g_As = (const R*)io->g_mat_As; g.g_Cs = (const R*)io->g_mat_Cs;
+    g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha;
+    g.d_m_in = (R*)io->d_m_in; g.d_P_in = (R*)io->d_P_in; g.partial = nullptr;
+    return g;
+}
+template <typename R>
+SmoothBwdArgs<R> mkb(const kvae_dims* d, const kvae_smooth_bwd* io) {
+    SmoothBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_ms = (const R*)io->g_mean_smooth; g.g_Ps = (const R*)io->g_cov_smooth;
+    g.g_zs = (const R*)io->g_zs; g.g_ares = (const R*)io->g_as_resampled;
+    g.d_m = (R*)io->d_mean_filt; g.d_P = (R*)io->d_cov_filt; g.d_mn = (R*)io->d_mean_pred;
+    g.d_Pn = (R*)io->d_cov_pred; g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs;
+    g.partial = nullptr;
+    return g;
+}
+template <typename R>
+ElboBwdArgs<R> mkb(const kvae_dims* d, const kvae_elbo_bwd* io) {
+    ElboBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.g_obs = (const R*)io->g_obs; g.g_trans = (const R*)io->g_trans;
+    g.g_post = (const R*)io->g_post;
+    g.d_a = (R*)io->d_a; g.d_ms = (R*)io->d_mean_smooth; g.d_Ps = (R*)io->d_cov_smooth;
+    g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs; g.partial = nullptr;
+    return g;
+}
+
+template <typename R, int N, int P, int K>
+int wfilter_fwd(const kvae_dims* d, const kvae_filter_fwd* io) {
+    FilterFwdArgs<R> g = mk<R>(d, io);
+    auto s = std::make_unique<wave::FilterScratch<R, N, P, K>>();
+    for (int b = 0; b < d->B; ++b) wave::filter_forward_sequence<R, N, P, K>(g, b, *s);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int wfilter_bwd(const kvae_dims* d, const kvae_filter_bwd* io) {
+    using PG = FilterParamGrads<N, P, K>;
+    FilterBwdArgs<R> g = mkb<R>(d, io);
+    auto s = std::make_unique<wave::FilterBwdScratch<R, N, P, K>>();
+    auto acc = std::make_unique<wave::FilterGradAcc<R, N, P, K>>();
+    acc->zero();
+    for (int b = 0; b < d->B; ++b) wave::filter_backward_sequence<R, N, P, K>(g, b, *s, *acc);
+    std::vector<R> row(PG::LEN);
+    acc->store(row.data());
+    put<R>(io->d_A_K, row.data() + PG::OFF_A, K * N * N);
+    put<R>(io->d_C_K, row.data() + PG::OFF_C, K * P * N);
+    put<R>(io->d_Q, row.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, row.data() + PG::OFF_R, P * P);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int wsmooth_fwd(const kvae_dims* d, const kvae_smooth_fwd* io) {
+    SmoothFwdArgs<R> g = mk<R>(d, io);
+    auto s = std::make_unique<wave::SmoothScratch<R, N, P>>();
+    for (int b = 0; b < d->B; ++b) wave::smooth_forward_sequence<R, N, P>(g, b, *s);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int wsmooth_bwd(const kvae_dims* d, const kvae_smooth_bwd* io) {
+    SmoothBwdArgs<R> g = mkb<R>(d, io);
+    auto s = std::make_unique<wave::SmoothBwdScratch<R, N, P>>();
+    wave::Acc<R, P * P> acc;
+    acc.zero();
+    for (int b = 0; b < d->B; ++b) wave::smooth_backward_sequence<R, N, P>(g, b, *s, acc);
+    std::vector<R> row(P * P);
+    acc.store(row.data());
+    put<R>(io->d_LR, row.data(), P * P);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int welbo_fwd(const kvae_dims* d, const kvae_elbo_fwd* io) {
+    ElboFwdArgs<R> g = mk<R>(d, io);
+    auto s = std::make_unique<wave::ElboScratch<R, N, P>>();
+    for (int b = 0; b < d->B; ++b) wave::elbo_forward_sequence<R, N, P>(g, b, *s);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int welbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
+    using PG = ElboParamGrads<N, P>;
+    ElboBwdArgs<R> g = mkb<R>(d, io);
+    auto s = std::make_unique<wave::ElboBwdScratch<R, N, P>>();
+    wave::ElboGradAcc<R, N, P> acc;
+    acc.zero();
+    for (int b = 0; b < d->B; ++b) wave::elbo_backward_sequence<R, N, P>(g, b, *s, acc);
+    std::vector<R> row(PG::LEN);
+    acc.store(row.data());
+    put<R>(io->d_Q, row.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, row.data() + PG::OFF_R, P * P);
+    put<R>(io->d_m0, row.data() + PG::OFF_M0, N);
+    put<R>(io->d_P0, row.data() + PG::OFF_P0, N * N);
+    return 0;
+}
+}  // namespace
+
+#define WAVE_DIM_LIST(X) X(32, 16, 8) X(16, 8, 4) X(6, 3, 2) X(4, 2, 3)
+
 #define DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(8, 4, 4)
 #define CASE(n_, p_, K_)                                          \
     if (d->n == n_ && d->p == p_ && d->K == K_) {                 \
@@ -176,6 +285,45 @@ int hostsim_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io) {
 int hostsim_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io) {
 #define FN elbo_bwd
     DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+
+#undef ARGS
+#define ARGS (d, io)
+int hostsim_wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io) {
+#define FN wfilter_fwd
+    WAVE_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io) {
+#define FN wfilter_bwd
+    WAVE_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io) {
+#define FN wsmooth_fwd
+    WAVE_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io) {
+#define FN wsmooth_bwd
+    WAVE_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io) {
+#define FN welbo_fwd
+    WAVE_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io) {
+#define FN welbo_bwd
+    WAVE_DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN
 }

@@ -23,27 +23,32 @@ def hostsim_lib():
     global _hostsim
     if _hostsim is None:
         src = os.path.join(HOSTSIM_DIR, "hostsim.cpp")
-        core = os.path.join(HERE, "..", "kalman_vae_amd", "csrc", "kalman_core.h")
+        csrc = os.path.join(HERE, "..", "kalman_vae_amd", "csrc")
+        deps = [src, os.path.join(csrc, "kalman_core.h"), os.path.join(csrc, "kalman_wave.h")]
         stale = (not os.path.exists(HOSTSIM_LIB)
-                 or os.path.getmtime(HOSTSIM_LIB) < max(os.path.getmtime(src),
-                                                        os.path.getmtime(core)))
+                 or os.path.getmtime(HOSTSIM_LIB) < max(os.path.getmtime(f) for f in deps))
         if stale:
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC",
                                    "-o", HOSTSIM_LIB, src])
-        _hostsim = capi.declare(C.CDLL(HOSTSIM_LIB), prefix="hostsim_", with_stream=False)
+        _hostsim = C.CDLL(HOSTSIM_LIB)
+        capi.declare(_hostsim, prefix="hostsim_", with_stream=False)
+        capi.declare(_hostsim, prefix="hostsim_wave_", with_stream=False)
     return _hostsim
 
 
 class Backend:
     def __init__(self, kind):
-        assert kind in ("hip", "hostsim")
+        """kind: "hip" (product library; picks the lane- or wavefront-per-sequence
+        kernels by dimension), "hostsim" (host build of the lane source) or
+        "hostsim_wave" (host build of the wavefront-per-sequence source)."""
+        assert kind in ("hip", "hostsim", "hostsim_wave")
         self.kind = kind
         self.device = torch.device("cuda:0" if kind == "hip" else "cpu")
         self.lib = capi.load() if kind == "hip" else hostsim_lib()
 
     def _call(self, name, dims, io, op=None):
-        if self.kind == "hostsim":
-            code = getattr(self.lib, "hostsim_" + name)(C.byref(dims), C.byref(io))
+        if self.kind != "hip":
+            code = getattr(self.lib, self.kind + "_" + name)(C.byref(dims), C.byref(io))
             assert code == 0, code
             return
         stream = torch.cuda.current_stream().cuda_stream
@@ -182,7 +187,8 @@ class Backend:
     def _any_K(n, p):
         """The smoother and ELBO kernels do not depend on K, but the dispatch
         table is keyed on (n,p,K): pick the K compiled for this (n,p)."""
-        return {(4, 2): 3, (2, 1): 2, (3, 2): 2, (8, 4): 4}[(n, p)]
+        return {(4, 2): 3, (2, 1): 2, (3, 2): 2, (8, 4): 4,
+                (32, 16): 8, (16, 8): 4, (6, 3): 2}[(n, p)]
 
 
 # -- random problem instances ------------------------------------------------

@@ -80,3 +80,43 @@ def test_elbo_f32_batches(be, B):
 
 def test_elbo_T1(be):
     KC.check_elbo(be, T=1, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=4)
+
+
+# -- wavefront-per-sequence kernels (dimensions outside the lane list) ---------
+WAVE_DIMS_F64 = [(6, 3, 2), (16, 8, 4)]
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS_F64)
+@pytest.mark.parametrize("mask_kind", ["none", "fractional"])
+def test_wave_filter_f64(be, n, p, K, mask_kind):
+    KC.check_filter(be, T=5, B=3, n=n, p=p, K=K, dtype=torch.float64, seed=n + p,
+                    mask_kind=mask_kind, burn_in=1)
+
+
+def test_wave_filter_options(be):
+    KC.check_filter(be, T=6, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=5, mask_kind="binary",
+                    symmetrize=False, burn_in=2, per_sequence_carry=True)
+    KC.check_filter(be, T=1, B=2, n=16, p=8, K=4, dtype=torch.float64, seed=6, mask_kind="binary",
+                    per_sequence_carry=True)
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS_F64)
+@pytest.mark.parametrize("sample", [False, True])
+def test_wave_smooth_f64(be, n, p, K, sample):
+    KC.check_smooth(be, T=5, B=3, n=n, p=p, K=K, dtype=torch.float64, seed=n, sample=sample,
+                    burn_in=1)
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS_F64)
+def test_wave_elbo_f64(be, n, p, K):
+    KC.check_elbo(be, T=5, B=3, n=n, p=p, K=K, dtype=torch.float64, seed=n + 1)
+
+
+def test_wave_large_state_f32(be):
+    """BASELINE config 4 shapes (z_dim 32, a_dim 16, K 8) at a test-sized T."""
+    KC.check_filter(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=1, mask_kind="binary",
+                    burn_in=2)
+    KC.check_smooth(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=2, sample=True,
+                    burn_in=2)
+    KC.check_elbo(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=3)
+    KC.check_elbo(be, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)

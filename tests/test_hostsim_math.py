@@ -65,3 +65,51 @@ def test_elbo_f64(be, n, p, K):
 def test_elbo_f32_and_T1(be):
     KC.check_elbo(be, T=20, B=4, n=4, p=2, K=3, dtype=torch.float32, seed=4)
     KC.check_elbo(be, T=1, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=4)
+
+
+# -- wavefront-per-sequence source (kalman_wave.h), same checks ----------------
+WAVE_DIMS = [(4, 2, 3), (6, 3, 2), (16, 8, 4), (32, 16, 8)]
+
+
+@pytest.fixture(scope="module")
+def bw():
+    return Backend("hostsim_wave")
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS)
+@pytest.mark.parametrize("mask_kind", ["none", "fractional"])
+def test_wave_filter_f64(bw, n, p, K, mask_kind):
+    KC.check_filter(bw, T=5, B=2, n=n, p=p, K=K, dtype=torch.float64, seed=n + p,
+                    mask_kind=mask_kind, burn_in=1)
+
+
+def test_wave_filter_options(bw):
+    KC.check_filter(bw, T=6, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=5, mask_kind="binary",
+                    symmetrize=False, burn_in=2, per_sequence_carry=True)
+    KC.check_filter(bw, T=1, B=2, n=16, p=8, K=4, dtype=torch.float64, seed=6, mask_kind="binary",
+                    per_sequence_carry=True)
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS)
+@pytest.mark.parametrize("sample", [False, True])
+def test_wave_smooth_f64(bw, n, p, K, sample):
+    KC.check_smooth(bw, T=5, B=2, n=n, p=p, K=K, dtype=torch.float64, seed=n, sample=sample,
+                    burn_in=1)
+
+
+def test_wave_smooth_options(bw):
+    KC.check_smooth(bw, T=6, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=11, sample=True,
+                    symmetrize=False, burn_in=2)
+    KC.check_smooth(bw, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=12, sample=True)
+
+
+@pytest.mark.parametrize("n,p,K", WAVE_DIMS)
+def test_wave_elbo_f64(bw, n, p, K):
+    KC.check_elbo(bw, T=5, B=2, n=n, p=p, K=K, dtype=torch.float64, seed=n + 1)
+
+
+def test_wave_f32_large_state(bw):
+    KC.check_filter(bw, T=8, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=1, mask_kind="binary")
+    KC.check_smooth(bw, T=8, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=2, sample=True)
+    KC.check_elbo(bw, T=8, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=3)
+    KC.check_elbo(bw, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)

@@ -56,6 +56,8 @@ def run_oracle(g):
 def test_oracle_matches_reference(name):
     g = Golden(name)
     tol = 1e-10 if g.dtype == torch.float64 else 2e-4
+    if g.stored_f32:
+        tol = 2e-6  # float64 run stored as float32
     obj, info, params = run_oracle(g)
     assert torch.equal(g["in.Q"], g["in.Q"].T.T)
     for ok, gk in OUT_MAP.items():
