@@ -57,11 +57,11 @@ def bouncing_ball_observations(T, B, p, device, seed):
     return torch.stack(out).to(device)
 
 
-def build_model(device, dtype, net):
+def build_model(device, dtype, net, n=4, p=2, K=3):
     from kalman_vae_amd import StateSpaceModel
-    ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network=net)
-    ssm.mat_Q = torch.eye(4)   # examples/train.py:73-74 of the reference
-    ssm.mat_R = torch.eye(2)
+    ssm = StateSpaceModel(a_dim=p, z_dim=n, K=K, dynamics_parameter_network=net)
+    ssm.mat_Q = torch.eye(n)   # examples/train.py:73-74 of the reference
+    ssm.mat_R = torch.eye(p)
     ssm = ssm.to(dtype).to(device).train()
     ssm.rng_parity = False      # one noise tensor per call instead of two per step
     ssm.check_numerics = False  # no host sync inside the step
@@ -92,7 +92,7 @@ def kernel_bytes(n, p, K, el):
     }
 
 
-def time_kernels(ssm, a, burn_in, iters=30):
+def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
     """Average duration of each HIP kernel of the step, measured with HIP events on
     the stream the kernels are launched on, by replaying each launch `iters` times
     on the tensors of a real forward/backward."""
@@ -104,9 +104,12 @@ def time_kernels(ssm, a, burn_in, iters=30):
     n, K = ssm.z_dim, ssm.K
     dt = a.dtype
     with torch.no_grad():
-        ssm.weight_model.clear_hidden_state()
-        alpha = torch.cat([torch.full((1, B, K), 1.0 / K, dtype=dt, device=dev),
-                           ssm.weight_model(a)]).contiguous()
+        if synthetic_alpha:
+            alpha = torch.softmax(torch.randn(T + 1, B, K, dtype=dt, device=dev), -1).contiguous()
+        else:
+            ssm.weight_model.clear_hidden_state()
+            alpha = torch.cat([torch.full((1, B, K), 1.0 / K, dtype=dt, device=dev),
+                               ssm.weight_model(a)]).contiguous()
         A_K, C_K = ssm.mat_A_K.contiguous(), ssm.mat_C_K.contiguous()
         Q, R = ssm.mat_Q.contiguous(), ssm.mat_R.contiguous()
         LR = torch.linalg.cholesky(R).contiguous()
@@ -180,24 +183,24 @@ def time_kernels(ssm, a, burn_in, iters=30):
     return out
 
 
-def cpu_baseline(T, B, net, burn_in, budget_s=20.0):
+def cpu_baseline(T, B, net, burn_in, n=4, p=2, K=3, budget_s=20.0):
     """The oracle (per-step PyTorch ops, autograd backward) on the host cores."""
     from kalman_vae_amd import StateSpaceModel
     from oracle import kalman_oracle as O
     torch.manual_seed(0)
-    ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network=net)
-    ssm.mat_Q = torch.eye(4)
-    ssm.mat_R = torch.eye(2)
+    ssm = StateSpaceModel(a_dim=p, z_dim=n, K=K, dynamics_parameter_network=net)
+    ssm.mat_Q = torch.eye(n)
+    ssm.mat_R = torch.eye(p)
     ssm.train()
-    a = bouncing_ball_observations(T, B, 2, "cpu", seed=0).requires_grad_(True)
+    a = bouncing_ball_observations(T, B, p, "cpu", seed=0).requires_grad_(True)
 
     def step():
         ssm.zero_grad(set_to_none=True)
         a.grad = None
         ssm.weight_model.clear_hidden_state()
-        eps = torch.randn(T, B, 4)
-        fn = (torch.randn(T, B, 4), torch.randn(T, B, 2))
-        sn = (torch.randn(T, B, 4), torch.randn(T, B, 2))
+        eps = torch.randn(T, B, n)
+        fn = (torch.randn(T, B, n), torch.randn(T, B, p))
+        sn = (torch.randn(T, B, n), torch.randn(T, B, p))
         obj, _ = O.kalman_objective(
             a, ssm.mat_A_K, ssm.mat_C_K, ssm.mat_Q, ssm.mat_R, ssm.initial_state_mean,
             ssm.initial_state_covariance, ssm.weight_model, eps, filter_noise=fn,
@@ -230,6 +233,13 @@ def main():
     ap.add_argument("--burn-in", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--state-dim", type=int, default=4)
+    ap.add_argument("--obs-dim", type=int, default=2)
+    ap.add_argument("--bases", type=int, default=3)
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="time only the six HIP kernels with synthetic mixing weights "
+                         "(softmax of N(0,1)); no PyTorch weight network, no autograd glue")
+    ap.add_argument("--kernel-iters", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -250,8 +260,9 @@ def main():
     T, B = args.seq_len, args.batch
     dtype = torch.float32
     torch.manual_seed(0)   # same initial parameters on every rank
-    ssm = build_model(dev, dtype, args.net)
-    a = bouncing_ball_observations(T, B, 2, dev, seed=1000 + rank).to(dtype).requires_grad_(True)
+    n, p, K = args.state_dim, args.obs_dim, args.bases
+    ssm = build_model(dev, dtype, args.net, n, p, K)
+    a = bouncing_ball_observations(T, B, p, dev, seed=1000 + rank).to(dtype).requires_grad_(True)
     bucket = FlatGradBucket(ssm.parameters()) if world > 1 else None
     sc = SampleControl()
 
@@ -269,14 +280,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    if args.kernels_only:
+        kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters, synthetic_alpha=True)
+        elapsed = sum(kt.values()) * args.steps
+    else:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -284,7 +299,6 @@ def main():
 
     result = None
     if rank == 0:
-        n, p, K = 4, 2, 3
         units = T * B
         ms_per_step = elapsed / args.steps * 1e3
         value = world * units * args.steps / elapsed
@@ -293,14 +307,17 @@ def main():
             "value": value, "unit": "sequence-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"bouncing-ball shapes T={T} a_dim=2 z_dim=4 K=3, "
-                                   f"{B} sequences per GPU, {args.net} weight network, "
-                                   "filter+RTS smoother+ELBO terms fwd+bwd (BASELINE config 2)",
+            "config": {"workload": f"bouncing-ball shapes T={T} a_dim={p} z_dim={n} K={K}, "
+                                   f"{B} sequences per GPU, "
+                                   + ("synthetic mixing weights, HIP kernels only, "
+                                      if args.kernels_only else f"{args.net} weight network, ")
+                                   + "filter+RTS smoother+ELBO terms fwd+bwd",
                        "seq_len": T, "batch_per_gpu": B, "global_batch": B * world,
                        "burn_in": args.burn_in, "parallelism": f"dp{world}"},
         }
         if not args.no_kernel_timing:
-            kt = time_kernels(ssm, a, args.burn_in)
+            if not args.kernels_only:
+                kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
             fl = flops_forward(n, p, K)
             kb = kernel_bytes(n, p, K, 4)
             kflops = {"filter_forward": fl["filter"], "filter_backward": 2 * fl["filter"],
@@ -328,8 +345,8 @@ def main():
                 "note": "sum of the six HIP kernels with precomputed mixing weights; excludes "
                         "the PyTorch weight network, noise draws and autograd glue",
             }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(T, B, args.net, args.burn_in)
+        if world == 1 and not args.no_cpu_baseline and not args.kernels_only:
+            result["cpu_baseline"] = cpu_baseline(T, B, args.net, args.burn_in, n, p, K)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

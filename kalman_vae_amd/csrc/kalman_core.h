@@ -300,6 +300,9 @@ struct FilterBwdArgs {
     const R *g_m, *g_P, *g_mn, *g_Pn, *g_As, *g_Cs;
     R *d_a, *d_alpha, *d_m_in, *d_P_in;
     R* partial;  // (rows, FilterParamGrads::LEN) per-wave partial sums
+    // wavefront-per-sequence variant only: gradients w.r.t. the mixed per-step
+    // matrices, (T+1,B,n,n) and (T+1,B,p,n); the mixing adjoint is a separate pass
+    R *bar_As, *bar_Cs;
 };
 
 template <typename R>

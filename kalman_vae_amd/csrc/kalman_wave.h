@@ -27,7 +27,17 @@
 #define KW_DEVICE 1
 #define KW_LANES 64
 #define KW_FOR(e, total) for (int e = (int)threadIdx.x; e < (total); e += KW_LANES)
-#define KW_SYNC() __syncthreads()
+// The workgroup is a single wavefront: its LDS instructions execute in program
+// order, so a later ds_read of any lane sees an earlier ds_write of any other
+// lane without waiting.  What is needed between two cooperative operations is
+// only that the COMPILER keeps their memory accesses in order (a wavefront-scope
+// fence emits no instruction) -- no s_barrier and, unlike __syncthreads(), no
+// wait for outstanding global stores.
+#define KW_SYNC()                                               \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
 #define KW_LANE0 (threadIdx.x == 0)
 #else
 #define KW_DEVICE 0
@@ -40,8 +50,22 @@
 namespace kvae {
 namespace wave {
 
+// LDS matrices are row-major with a leading dimension of cols + 1: a column
+// walk (transposed operand, symmetrisation, triangular solves) then strides by
+// an odd number of words and is free of bank conflicts; with ld = cols = 32
+// every element of a column sits in the same bank.  Vectors (cols == 1) are
+// contiguous.  Element-wise operations run over the padded storage (the pad
+// words are never read by anything that matters).
+constexpr int ld(int cols) { return cols > 1 ? cols + 1 : 1; }
+constexpr int msize(int rows, int cols) { return rows * ld(cols); }
+// padded offset of logical element e of a (rows x COLS) matrix
+template <int COLS>
+KV_HD int pad_index(int e) {
+    return (e / COLS) * ld(COLS) + (e % COLS);
+}
+
 // ---------------------------------------------------------------------------
-// cooperative operations on LDS-resident row-major matrices
+// cooperative operations on LDS-resident matrices
 // ---------------------------------------------------------------------------
 template <typename R>
 KV_HD R wsum(R v) {
@@ -53,22 +77,72 @@ KV_HD R wsum(R v) {
 }
 
 // C (M x N) {=,+=,-=} op(A) op(B), contraction length Kd (see kvae::gemm).
+// A is stored M x Kd (Kd x M when TA), B is stored Kd x N (N x Kd when TB).
 template <typename R, int M, int Kd, int N, bool TA, bool TB, int MODE>
-KV_HD void gemm(const R* A, const R* Bm, R* C) {
+KV_HD void gemm_valu(const R* A, const R* Bm, R* C) {
+    constexpr int lda = ld(TA ? M : Kd), ldb = ld(TB ? Kd : N), ldc = ld(N);
     KW_FOR(e, M * N) {
         const int i = e / N, j = e % N;
         R acc = R(0);
 #pragma unroll 8
         for (int k = 0; k < Kd; ++k) {
-            const R a = TA ? A[k * M + i] : A[i * Kd + k];
-            const R b = TB ? Bm[j * Kd + k] : Bm[k * N + j];
+            const R a = TA ? A[k * lda + i] : A[i * lda + k];
+            const R b = TB ? Bm[j * ldb + k] : Bm[k * ldb + j];
             acc += a * b;
         }
-        if (MODE == 0) C[e] = acc;
-        if (MODE == 1) C[e] += acc;
-        if (MODE == 2) C[e] -= acc;
+        R* c = C + i * ldc + j;
+        if (MODE == 0) *c = acc;
+        if (MODE == 1) *c += acc;
+        if (MODE == 2) *c -= acc;
     }
     KW_SYNC();
+}
+
+#if KW_DEVICE
+// fp32 products with M, N <= 32 on the matrix core: v_mfma_f32_32x32x2_f32
+// (exact fp32 multiply-add chain in k order).  Lane l supplies A[l&31][2kk+(l>>5)]
+// and B[2kk+(l>>5)][l&31]; rows/columns beyond M/N and k beyond Kd are fed as
+// zeros.  Accumulator register r of lane l holds C[(r&3)+8(r>>2)+4(l>>5)][l&31].
+template <int M, int Kd, int N, bool TA, bool TB, int MODE>
+__device__ __forceinline__ void gemm_mfma(const float* A, const float* Bm, float* C) {
+    static_assert(M <= 32 && N <= 32, "one 32x32 accumulator tile");
+    constexpr int lda = ld(TA ? M : Kd), ldb = ld(TB ? Kd : N), ldc = ld(N);
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < (Kd + 1) / 2; ++kk) {
+        const int k = 2 * kk + h;
+        float a = 0.f, b = 0.f;
+        if (i < M && k < Kd) a = TA ? A[k * lda + i] : A[i * lda + k];
+        if (i < N && k < Kd) b = TB ? Bm[i * ldb + k] : Bm[k * ldb + i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M && i < N) {
+            float* c = C + row * ldc + i;
+            if (MODE == 0) *c = acc[r];
+            if (MODE == 1) *c += acc[r];
+            if (MODE == 2) *c -= acc[r];
+        }
+    }
+    KW_SYNC();
+}
+#endif
+
+template <typename R, int M, int Kd, int N, bool TA, bool TB, int MODE>
+KV_HD void gemm(const R* A, const R* Bm, R* C) {
+#if KW_DEVICE
+    if constexpr (sizeof(R) == 4 && M * N >= 256 && M <= 32 && N <= 32 && Kd >= 8) {
+        gemm_mfma<M, Kd, N, TA, TB, MODE>(A, Bm, C);
+        return;
+    }
+#endif
+    gemm_valu<R, M, Kd, N, TA, TB, MODE>(A, Bm, C);
 }
 
 template <typename R, int M, int N, bool TA, int MODE>
@@ -79,7 +153,7 @@ KV_HD void gemv(const R* A, const R* x, R* y) {
 // C (M x N) += s x y^T
 template <typename R, int M, int N>
 KV_HD void outer_add(R s, const R* x, const R* y, R* C) {
-    KW_FOR(e, M * N) C[e] += s * x[e / N] * y[e % N];
+    KW_FOR(e, M * N) C[pad_index<N>(e)] += s * x[e / N] * y[e % N];
     KW_SYNC();
 }
 
@@ -121,9 +195,9 @@ KV_HD void symmetrize_inplace(R* X) {
     KW_FOR(e, N * N) {
         const int i = e / N, j = e % N;
         if (i < j) {
-            const R v = (X[i * N + j] + X[j * N + i]) / R(2);
-            X[i * N + j] = v;
-            X[j * N + i] = v;
+            const R v = (X[i * ld(N) + j] + X[j * ld(N) + i]) / R(2);
+            X[i * ld(N) + j] = v;
+            X[j * ld(N) + i] = v;
         }
     }
     KW_SYNC();
@@ -156,42 +230,70 @@ KV_HD void gstore_zero(R* p) {
     KW_FOR(e, Len) p[e] = R(0);
 }
 
-template <typename R, int K, int Len>
+// matrix variants: global memory is dense row-major, LDS is padded
+template <typename R, int ROWS, int COLS>
+KV_HD void gload_mat(const R* p, R* x) {
+    KW_FOR(e, ROWS * COLS) x[pad_index<COLS>(e)] = p[e];
+    KW_SYNC();
+}
+template <typename R, int ROWS, int COLS>
+KV_HD void gload_mat_or_zero(const R* base, long off, R* x) {
+    KW_FOR(e, ROWS * COLS) x[pad_index<COLS>(e)] = base ? base[off + e] : R(0);
+    KW_SYNC();
+}
+template <typename R, int ROWS, int COLS>
+KV_HD void gload_mat_add(const R* base, long off, R* x) {
+    if (base) {
+        KW_FOR(e, ROWS * COLS) x[pad_index<COLS>(e)] += base[off + e];
+    }
+    KW_SYNC();
+}
+template <typename R, int ROWS, int COLS>
+KV_HD void gstore_mat(R* p, const R* x) {
+    KW_FOR(e, ROWS * COLS) p[e] = x[pad_index<COLS>(e)];
+    KW_SYNC();
+}
+
+template <typename R, int K, int ROWS, int COLS>
 KV_HD void mix(const R* w, const R* bases, R* out) {
+    constexpr int Len = ROWS * COLS;
     KW_FOR(e, Len) {
         R acc = R(0);
 #pragma unroll
         for (int k = 0; k < K; ++k) acc += w[k] * bases[k * Len + e];
-        out[e] = acc;
+        out[pad_index<COLS>(e)] = acc;
     }
     KW_SYNC();
 }
 
 // Right-looking Cholesky, lower factor; S is destroyed (used as work space).
 // Only the lower triangle of S is read.  Returns false on a pivot <= 0.
+// Generic form (any real type, also the host build).
 template <typename R, int N>
-KV_HD bool cholesky(R* S, R* L) {
+KV_HD bool cholesky_generic(R* S, R* L) {
+    constexpr int l = ld(N);
     bool ok = true;
     for (int j = 0; j < N; ++j) {
-        R d = S[j * N + j];  // same address in every lane
+        R d = S[j * l + j];  // same address in every lane
         if (!(d > R(0))) {
             ok = false;
             d = R(1);
         }
         const R ljj = sqrt(d);
         const R inv = R(1) / ljj;
-        KW_SYNC();  // everyone has read the pivot before column j is overwritten
+        KW_SYNC();
         KW_FOR(i, N) {
-            if (i < j) L[i * N + j] = R(0);
-            if (i == j) L[i * N + j] = ljj;
-            if (i > j) L[i * N + j] = S[i * N + j] * inv;
+            if (i < j) L[i * l + j] = R(0);
+            if (i == j) L[i * l + j] = ljj;
+            if (i > j) L[i * l + j] = S[i * l + j] * inv;
         }
         KW_SYNC();
-        // trailing update of the lower triangle: S[i][k] -= L[i][j] L[k][j], i >= k > j
-        const int rem = N - 1 - j;
-        KW_FOR(e, rem * rem) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (i >= k) S[i * N + k] -= L[i * N + j] * L[k * N + j];
+        // trailing update, one lane per row: S[i][k] -= L[i][j] L[k][j], i >= k > j
+        KW_FOR(i, N) {
+            if (i > j) {
+                const R lij = L[i * l + j];
+                for (int k = j + 1; k <= i; ++k) S[i * l + k] -= lij * L[k * l + j];
+            }
         }
         KW_SYNC();
     }
@@ -200,28 +302,148 @@ KV_HD bool cholesky(R* S, R* L) {
 
 // Inverse of a lower-triangular matrix; lane j builds column j.
 template <typename R, int N>
-KV_HD void tri_lower_inverse(const R* L, R* Li) {
+KV_HD void tri_lower_inverse_generic(const R* L, R* Li) {
+    constexpr int l = ld(N);
     KW_FOR(j, N) {
         for (int i = 0; i < N; ++i) {
             if (i < j) {
-                Li[i * N + j] = R(0);
+                Li[i * l + j] = R(0);
             } else if (i == j) {
-                Li[i * N + j] = R(1) / L[i * N + i];
+                Li[i * l + j] = R(1) / L[i * l + i];
             } else {
                 R s = R(0);
-                for (int k = j; k < i; ++k) s += L[i * N + k] * Li[k * N + j];
-                Li[i * N + j] = -s / L[i * N + i];
+                for (int k = j; k < i; ++k) s += L[i * l + k] * Li[k * l + j];
+                Li[i * l + j] = -s / L[i * l + i];
             }
         }
     }
     KW_SYNC();
 }
 
-// Si = S^-1 through the Cholesky factor; S is destroyed; L and Li are outputs.
+#if KW_DEVICE
+// fp32, register-resident: lane i keeps row i of the factor in N registers and
+// the other rows' elements arrive through v_readlane (a scalar operand of the
+// FMA), so the factorisation needs no LDS traffic and no barrier until the
+// result is written back.  The loops are fully unrolled (register arrays must be
+// indexed with constants); the functions are noinline so that each size exists
+// once per kernel.
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// in: S (lower triangle read); out: L and, if Li != nullptr, L^-1 (both N x N, padded)
+template <int N>
+__device__ __noinline__ bool cholesky_inverse_f32(const float* S, float* L, float* Li) {
+    static_assert(N <= 64, "one row per lane");
+    constexpr int l = ld(N);
+    const int lane = threadIdx.x;
+    const int i = lane < N ? lane : N - 1;
+    float row[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) row[k] = S[i * l + k];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float s = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= row[k] * lane_bcast(row[k], j);
+        float d = lane_bcast(s, j);
+        if (!(d > 0.f)) {
+            ok = false;
+            d = 1.f;
+        }
+        const float ljj = sqrtf(d);
+        const float inv = 1.f / ljj;
+        row[j] = (i == j) ? ljj : (i > j ? s * inv : 0.f);
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) L[lane * l + k] = row[k];
+    }
+    if (Li) {
+        // own diagonal element without a run-time register index
+        float diag = 1.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) diag = (i == k) ? row[k] : diag;
+        const float rdiag = 1.f / diag;
+        float x[N];  // column `lane` of L^-1
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            float acc = (lane == r) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= lane_bcast(row[k], r) * x[k];
+            x[r] = acc * lane_bcast(rdiag, r);
+        }
+        if (lane < N) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) Li[r * l + lane] = x[r];
+        }
+    }
+    KW_SYNC();
+    return ok;
+}
+
+template <int N>
+__device__ __noinline__ void tri_lower_inverse_f32(const float* L, float* Li) {
+    constexpr int l = ld(N);
+    const int lane = threadIdx.x;
+    const int i = lane < N ? lane : N - 1;
+    float row[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) row[k] = L[i * l + k];
+    float diag = 1.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) diag = (i == k) ? row[k] : diag;
+    const float rdiag = 1.f / diag;
+    float x[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        float acc = (lane == r) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc -= lane_bcast(row[k], r) * x[k];
+        x[r] = acc * lane_bcast(rdiag, r);
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) Li[r * l + lane] = x[r];
+    }
+    KW_SYNC();
+}
+#endif
+
+// S may be destroyed.
+template <typename R, int N>
+KV_HD bool cholesky(R* S, R* L) {
+#if KW_DEVICE
+    if constexpr (sizeof(R) == 4) return cholesky_inverse_f32<N>(S, L, nullptr);
+#endif
+    return cholesky_generic<R, N>(S, L);
+}
+
+template <typename R, int N>
+KV_HD void tri_lower_inverse(const R* L, R* Li) {
+#if KW_DEVICE
+    if constexpr (sizeof(R) == 4) {
+        tri_lower_inverse_f32<N>(L, Li);
+        return;
+    }
+#endif
+    tri_lower_inverse_generic<R, N>(L, Li);
+}
+
+// Si = S^-1 through the Cholesky factor; S may be destroyed; L and Li are outputs.
 template <typename R, int N>
 KV_HD bool spd_inverse(R* S, R* Si, R* L, R* Li) {
-    const bool ok = cholesky<R, N>(S, L);
-    tri_lower_inverse<R, N>(L, Li);
+    bool ok;
+#if KW_DEVICE
+    if constexpr (sizeof(R) == 4) {
+        ok = cholesky_inverse_f32<N>(S, L, Li);
+    } else
+#endif
+    {
+        ok = cholesky_generic<R, N>(S, L);
+        tri_lower_inverse_generic<R, N>(L, Li);
+    }
     gemm<R, N, N, N, true, false, 0>(Li, Li, Si);
     return ok;
 }
@@ -233,17 +455,17 @@ KV_HD void cholesky_adjoint_add(const R* L, const R* Li, const R* Lbar, R* X, R*
         const int i = e / N, j = e % N;
         R acc = R(0);
         if (i >= j) {
-            for (int k = i; k < N; ++k) acc += L[k * N + i] * Lbar[k * N + j];
+            for (int k = i; k < N; ++k) acc += L[k * ld(N) + i] * Lbar[k * ld(N) + j];
             if (i == j) acc *= R(0.5);
         }
-        X[e] = acc;
+        X[pad_index<N>(e)] = acc;
     }
     KW_SYNC();
     gemm<R, N, N, N, true, false, 0>(Li, X, Y);   // L^-T X
     gemm<R, N, N, N, false, false, 0>(Y, Li, X);  // ... L^-1
     KW_FOR(e, N * N) {
         const int i = e / N, j = e % N;
-        Sacc[e] += (X[i * N + j] + X[j * N + i]) * R(0.5);
+        Sacc[pad_index<N>(e)] += (X[i * ld(N) + j] + X[j * ld(N) + i]) * R(0.5);
     }
     KW_SYNC();
 }
@@ -252,11 +474,11 @@ KV_HD void cholesky_adjoint_add(const R* L, const R* Li, const R* Lbar, R* X, R*
 template <typename R, int N>
 KV_HD R half_logdet(const R* L) {
     R acc = R(0);
-    KW_FOR(i, N) acc += log(L[i * N + i]);
+    KW_FOR(i, N) acc += log(L[i * ld(N) + i]);
     return wsum<R>(acc);
 }
 
-// Register-resident accumulator of LEN values distributed over the lanes.
+// Register-resident accumulator of LEN logical values distributed over the lanes.
 template <typename R, int LEN>
 struct Acc {
     static constexpr int PER = (LEN + KW_LANES - 1) / KW_LANES;
@@ -265,16 +487,17 @@ struct Acc {
         KV_UNROLL
         for (int q = 0; q < PER; ++q) v[q] = R(0);
     }
-    // this += s * x (x in LDS, LEN values)
+    // this += s * x, x a (LEN/COLS x COLS) matrix in LDS
+    template <int COLS>
     KV_HD void axpy(R s, const R* x) {
 #if KW_DEVICE
         KV_UNROLL
         for (int q = 0; q < PER; ++q) {
             const int e = (int)threadIdx.x + KW_LANES * q;
-            if (e < LEN) v[q] += s * x[e];
+            if (e < LEN) v[q] += s * x[pad_index<COLS>(e)];
         }
 #else
-        for (int e = 0; e < LEN; ++e) v[e] += s * x[e];
+        for (int e = 0; e < LEN; ++e) v[e] += s * x[pad_index<COLS>(e)];
 #endif
     }
     KV_HD void store(R* out) const {
@@ -300,27 +523,37 @@ KV_HD void raise_status(int* status, int st) {
     }
 }
 
+// zero a whole scratch struct (pad words included) once per kernel
+template <typename S, typename R>
+KV_HD void clear_scratch(S& s) {
+    R* w = reinterpret_cast<R*>(&s);
+    KW_FOR(e, (int)(sizeof(S) / sizeof(R))) w[e] = R(0);
+    KW_SYNC();
+}
+
 // ---------------------------------------------------------------------------
 // Filter
 // ---------------------------------------------------------------------------
 template <typename R, int N, int P, int K>
 struct FilterScratch {
-    R Rm[P * P], Q[N * N], mp[N], Pp[N * N], m[N], Pf[N * N];
-    R w[K], wn[K], a[P], C[P * N], An[N * N];
-    R M[P * N], S[P * P], Si[P * P], LS[P * P], LiS[P * P], F[N * P], G[N * P], r[P];
-    R T1[N * N];
+    static constexpr int NN = msize(N, N), PN = msize(P, N), NP = msize(N, P), PP = msize(P, P);
+    R Rm[PP], Q[NN], mp[N], Pp[NN], m[N], Pf[NN];
+    R w[K], wn[K], a[P], C[PN], An[NN];
+    R M[PN], S[PP], Si[PP], LS[PP], LiS[PP], F[NP], G[NP], r[P];
+    R T1[NN];
 };
 template <typename R, int N, int P, int K>
 struct FilterBwdScratch : FilterScratch<R, N, P, K> {
-    R mb[N], Pb[N * N], mpb[N], Ppb[N * N], Ab[N * N], Cb[P * N], T2[N * N];
-    R mob[N], Pob[N * N], Gb[N * P], rb[P], Mb[P * N], Fb[N * P], Sib[P * P], Sb[P * P],
-        T3[P * P], CPt[P * N], T4[P * N], dwn[K], da[K];
+    using B0 = FilterScratch<R, N, P, K>;
+    R mb[N], Pb[B0::NN], mpb[N], Ppb[B0::NN], Ab[B0::NN], Cb[B0::PN], T2[B0::NN];
+    R mob[N], Pob[B0::NN], Gb[B0::NP], rb[P], Mb[B0::PN], Fb[B0::NP], Sib[B0::PP], Sb[B0::PP],
+        T3[B0::PP], CPt[B0::PN], T4[B0::PN];
 };
 
 template <typename R, int N, int P, int K>
 KV_HD bool update_terms(FilterScratch<R, N, P, K>& s) {
     gemm<R, P, N, N, false, false, 0>(s.C, s.Pp, s.M);
-    vcopy<R, P * P>(s.Rm, s.S);
+    vcopy<R, msize(P, P)>(s.Rm, s.S);
     gemm<R, P, N, P, false, true, 1>(s.M, s.C, s.S);
     const bool ok = spd_inverse<R, P>(s.S, s.Si, s.LS, s.LiS);
     gemm<R, N, N, P, false, true, 0>(s.Pp, s.C, s.F);
@@ -332,156 +565,129 @@ KV_HD bool update_terms(FilterScratch<R, N, P, K>& s) {
 
 template <typename R, int N, int P, int K>
 KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b, FilterScratch<R, N, P, K>& s) {
+    constexpr int NN = msize(N, N);
     const long B = g.B;
-    gload<R, P * P>(g.Rm, s.Rm);
-    gload<R, N * N>(g.Q, s.Q);
+    clear_scratch<FilterScratch<R, N, P, K>, R>(s);
+    gload_mat<R, P, P>(g.Rm, s.Rm);
+    gload_mat<R, N, N>(g.Q, s.Q);
     if (g.carry_per_sequence) {
         gload<R, N>(g.m_in + (long)b * N, s.mp);
-        gload<R, N * N>(g.P_in + (long)b * N * N, s.Pp);
+        gload_mat<R, N, N>(g.P_in + (long)b * N * N, s.Pp);
     } else {
         gload<R, N>(g.m_in, s.mp);
-        gload<R, N * N>(g.P_in, s.Pp);
+        gload_mat<R, N, N>(g.P_in, s.Pp);
     }
     gload<R, K>(g.alpha + (long)b * K, s.w);
     if (g.As) {
-        mix<R, K, N * N>(s.w, g.A_K, s.An);
-        gstore<R, N * N>(g.As + (long)b * N * N, s.An);
+        mix<R, K, N, N>(s.w, g.A_K, s.An);
+        gstore_mat<R, N, N>(g.As + (long)b * N * N, s.An);
     }
     int st = 0;
     for (int t = 0; t < g.T; ++t) {
         const long tb = (long)t * B + b;
         gload<R, K>(g.alpha + (tb + B) * K, s.wn);
         gload<R, P>(g.a + tb * P, s.a);
-        mix<R, K, P * N>(s.w, g.C_K, s.C);
-        mix<R, K, N * N>(s.wn, g.A_K, s.An);
-        if (g.Cs) gstore<R, P * N>(g.Cs + tb * P * N, s.C);
-        if (g.As) gstore<R, N * N>(g.As + (tb + B) * N * N, s.An);
+        mix<R, K, P, N>(s.w, g.C_K, s.C);
+        mix<R, K, N, N>(s.wn, g.A_K, s.An);
+        if (g.Cs) gstore_mat<R, P, N>(g.Cs + tb * P * N, s.C);
+        if (g.As) gstore_mat<R, N, N>(g.As + (tb + B) * N * N, s.An);
         if (!update_terms<R, N, P, K>(s)) st |= ST_NONPD_INNOVATION;
 
         vcopy<R, N>(s.mp, s.m);
         gemv<R, N, P, false, 1>(s.G, s.r, s.m);
-        vcopy<R, N * N>(s.Pp, s.Pf);
+        vcopy<R, NN>(s.Pp, s.Pf);
         gemm<R, N, P, N, false, false, 2>(s.G, s.M, s.Pf);
         if (g.mask) {
             const R mu = g.mask[tb];
             axpby<R, N>(mu, s.m, R(1) - mu, s.mp, s.m);
-            axpby<R, N * N>(mu, s.Pf, R(1) - mu, s.Pp, s.Pf);
+            axpby<R, NN>(mu, s.Pf, R(1) - mu, s.Pp, s.Pf);
         }
         if (g.symmetrize) symmetrize_inplace<R, N>(s.Pf);
         gemv<R, N, N, false, 0>(s.An, s.m, s.mp);
         gemm<R, N, N, N, false, false, 0>(s.An, s.Pf, s.T1);
-        vcopy<R, N * N>(s.Q, s.Pp);
+        vcopy<R, NN>(s.Q, s.Pp);
         gemm<R, N, N, N, false, true, 1>(s.T1, s.An, s.Pp);
         if (g.symmetrize) symmetrize_inplace<R, N>(s.Pp);
         gstore<R, N>(g.m + tb * N, s.m);
-        gstore<R, N * N>(g.Pf + tb * N * N, s.Pf);
+        gstore_mat<R, N, N>(g.Pf + tb * N * N, s.Pf);
         gstore<R, N>(g.mn + tb * N, s.mp);
-        gstore<R, N * N>(g.Pn + tb * N * N, s.Pp);
+        gstore_mat<R, N, N>(g.Pn + tb * N * N, s.Pp);
         vcopy<R, K>(s.wn, s.w);
     }
     if (g.Cs) {
-        mix<R, K, P * N>(s.w, g.C_K, s.C);
-        gstore<R, P * N>(g.Cs + ((long)g.T * B + b) * P * N, s.C);
+        mix<R, K, P, N>(s.w, g.C_K, s.C);
+        gstore_mat<R, P, N>(g.Cs + ((long)g.T * B + b) * P * N, s.C);
     }
     raise_status(g.status, st);
 }
 
+// Sums over t of the noise-covariance gradients of one sequence.  The basis
+// gradients and d_alpha are NOT accumulated here: the kernel stores the
+// gradients w.r.t. the mixed matrices A_t, C_t (bar_As, bar_Cs) and a separate
+// streaming pass contracts them with alpha and the bases (mix_adjoint_*), which
+// keeps ~190 accumulator registers out of this kernel.
 template <typename R, int N, int P, int K>
 struct FilterGradAcc {
-    Acc<R, K * N * N> dA;
-    Acc<R, K * P * N> dC;
+    static constexpr int LEN = N * N + P * P;
     Acc<R, N * N> dQ;
     Acc<R, P * P> dR;
     KV_HD void zero() {
-        dA.zero();
-        dC.zero();
         dQ.zero();
         dR.zero();
     }
     KV_HD void store(R* row) const {
-        using PG = FilterParamGrads<N, P, K>;
-        dA.store(row + PG::OFF_A);
-        dC.store(row + PG::OFF_C);
-        dQ.store(row + PG::OFF_Q);
-        dR.store(row + PG::OFF_R);
+        dQ.store(row);
+        dR.store(row + N * N);
     }
 };
-
-// acc.dX[k*Len + e] += w[k] * x[e]
-template <typename R, int K, int Len>
-KV_HD void acc_mix(Acc<R, K * Len>& acc, const R* w, const R* x) {
-#if KW_DEVICE
-    constexpr int PER = Acc<R, K * Len>::PER;
-    KV_UNROLL
-    for (int q = 0; q < PER; ++q) {
-        const int idx = (int)threadIdx.x + KW_LANES * q;
-        if (idx < K * Len) acc.v[q] += w[idx / Len] * x[idx % Len];
-    }
-#else
-    for (int idx = 0; idx < K * Len; ++idx) acc.v[idx] += w[idx / Len] * x[idx % Len];
-#endif
-}
-
-// out[k] = <x, bases[k]> for k < K (bases in global memory)
-template <typename R, int K, int Len>
-KV_HD void basis_dots(const R* x, const R* bases, R* out) {
-    for (int k = 0; k < K; ++k) {
-        R acc = R(0);
-        KW_FOR(e, Len) acc += x[e] * bases[k * Len + e];
-        acc = wsum<R>(acc);
-        if (KW_LANE0) out[k] = acc;
-    }
-    KW_SYNC();
-}
 
 template <typename R, int N, int P, int K>
 KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b,
                                     FilterBwdScratch<R, N, P, K>& s,
                                     FilterGradAcc<R, N, P, K>& acc) {
+    constexpr int NN = msize(N, N), PP = msize(P, P), NP = msize(N, P);
     const FilterFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
-    gload<R, P * P>(f.Rm, s.Rm);
-    vzero<R, N>(s.mpb);
-    vzero<R, N * N>(s.Ppb);
+    clear_scratch<FilterBwdScratch<R, N, P, K>, R>(s);
+    gload_mat<R, P, P>(f.Rm, s.Rm);
     {
-        gload_or_zero<R, P * N>(g.g_Cs, ((long)T * B + b) * P * N, s.Cb);
-        gload<R, K>(f.alpha + ((long)T * B + b) * K, s.w);
-        basis_dots<R, K, P * N>(s.Cb, f.C_K, s.dwn);
-        acc_mix<R, K, P * N>(acc.dC, s.w, s.Cb);
+        // C_T only feeds the returned mat_Cs[T]
+        gload_mat_or_zero<R, P, N>(g.g_Cs, ((long)T * B + b) * P * N, s.Cb);
+        gstore_mat<R, P, N>(g.bar_Cs + ((long)T * B + b) * P * N, s.Cb);
     }
     for (int t = T - 1; t >= 0; --t) {
         const long tb = (long)t * B + b;
         gload<R, K>(f.alpha + tb * K, s.w);
         gload<R, K>(f.alpha + (tb + B) * K, s.wn);
         gload<R, P>(f.a + tb * P, s.a);
-        mix<R, K, P * N>(s.w, f.C_K, s.C);
-        mix<R, K, N * N>(s.wn, f.A_K, s.An);
+        mix<R, K, P, N>(s.w, f.C_K, s.C);
+        mix<R, K, N, N>(s.wn, f.A_K, s.An);
         if (t > 0) {
             gload<R, N>(f.mn + (tb - B) * N, s.mp);
-            gload<R, N * N>(f.Pn + (tb - B) * N * N, s.Pp);
+            gload_mat<R, N, N>(f.Pn + (tb - B) * N * N, s.Pp);
         } else if (f.carry_per_sequence) {
             gload<R, N>(f.m_in + (long)b * N, s.mp);
-            gload<R, N * N>(f.P_in + (long)b * N * N, s.Pp);
+            gload_mat<R, N, N>(f.P_in + (long)b * N * N, s.Pp);
         } else {
             gload<R, N>(f.m_in, s.mp);
-            gload<R, N * N>(f.P_in, s.Pp);
+            gload_mat<R, N, N>(f.P_in, s.Pp);
         }
         gload<R, N>(f.m + tb * N, s.m);
-        gload<R, N * N>(f.Pf + tb * N * N, s.Pf);
+        gload_mat<R, N, N>(f.Pf + tb * N * N, s.Pf);
 
         gload_or_zero<R, N>(g.g_m, tb * N, s.mb);
-        gload_or_zero<R, N * N>(g.g_P, tb * N * N, s.Pb);
+        gload_mat_or_zero<R, N, N>(g.g_P, tb * N * N, s.Pb);
         gload_add<R, N>(g.g_mn, tb * N, s.mpb);
-        gload_add<R, N * N>(g.g_Pn, tb * N * N, s.Ppb);
+        gload_mat_add<R, N, N>(g.g_Pn, tb * N * N, s.Ppb);
         if (t < g.burn_in) {
             vzero<R, N>(s.mb);
-            vzero<R, N * N>(s.Pb);
+            vzero<R, NN>(s.Pb);
             vzero<R, N>(s.mpb);
-            vzero<R, N * N>(s.Ppb);
+            vzero<R, NN>(s.Ppb);
         }
         // time update adjoint
-        gload_or_zero<R, N * N>(g.g_As, (tb + B) * N * N, s.Ab);
+        gload_mat_or_zero<R, N, N>(g.g_As, (tb + B) * N * N, s.Ab);
         if (f.symmetrize) symmetrize_inplace<R, N>(s.Ppb);
         outer_add<R, N, N>(R(1), s.mpb, s.m, s.Ab);
         gemm<R, N, N, N, false, true, 0>(s.An, s.Pf, s.T1);
@@ -491,24 +697,24 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b,
         gemv<R, N, N, true, 1>(s.An, s.mpb, s.mb);
         gemm<R, N, N, N, true, false, 0>(s.An, s.Ppb, s.T2);
         gemm<R, N, N, N, false, false, 1>(s.T2, s.An, s.Pb);
-        acc.dQ.axpy(R(1), s.Ppb);
+        acc.dQ.template axpy<N>(R(1), s.Ppb);
 
         // measurement update adjoint
         update_terms<R, N, P, K>(s);
         const R mu = f.mask ? f.mask[tb] : R(1);
         const R nu = R(1) - mu;
         if (f.symmetrize) symmetrize_inplace<R, N>(s.Pb);
-        gload_or_zero<R, P * N>(g.g_Cs, tb * P * N, s.Cb);
+        gload_mat_or_zero<R, P, N>(g.g_Cs, tb * P * N, s.Cb);
         KW_FOR(i, N) {
             s.mob[i] = mu * s.mb[i];
             s.mpb[i] = nu * s.mb[i] + mu * s.mb[i];
         }
-        KW_FOR(i, N * N) {
+        KW_FOR(i, NN) {
             s.Pob[i] = mu * s.Pb[i];
             s.Ppb[i] = nu * s.Pb[i] + mu * s.Pb[i];
         }
         KW_SYNC();
-        vzero<R, N * P>(s.Gb);
+        vzero<R, NP>(s.Gb);
         outer_add<R, N, P>(R(1), s.mob, s.r, s.Gb);
         gemv<R, P, N, true, 0>(s.G, s.mob, s.rb);
         gstore<R, P>(g.d_a + tb * P, s.rb);
@@ -522,7 +728,7 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b,
         gemm<R, P, N, P, true, false, 0>(s.F, s.Gb, s.Sib);
         gemm<R, P, P, P, true, false, 0>(s.Si, s.Sib, s.T3);
         gemm<R, P, P, P, false, true, 0>(s.T3, s.Si, s.Sb);
-        vscale<R, P * P>(R(-1), s.Sb);
+        vscale<R, PP>(R(-1), s.Sb);
         gemm<R, N, P, N, false, false, 1>(s.Fb, s.C, s.Ppb);
         gemm<R, P, N, N, true, false, 1>(s.Fb, s.Pp, s.Cb);
         gemm<R, P, N, N, false, true, 0>(s.C, s.Pp, s.CPt);
@@ -530,28 +736,19 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b,
         gemm<R, P, P, N, true, false, 1>(s.Sb, s.M, s.Cb);
         gemm<R, P, P, N, false, false, 0>(s.Sb, s.C, s.T4);
         gemm<R, N, P, N, true, false, 1>(s.C, s.T4, s.Ppb);
-        acc.dR.axpy(R(1), s.Sb);
+        acc.dR.template axpy<P>(R(1), s.Sb);
 
-        // mixing adjoint
-        basis_dots<R, K, N * N>(s.Ab, f.A_K, s.da);
-        KW_FOR(k, K) s.da[k] += s.dwn[k];
-        KW_SYNC();
-        gstore<R, K>(g.d_alpha + (tb + B) * K, s.da);
-        acc_mix<R, K, N * N>(acc.dA, s.wn, s.Ab);
-        basis_dots<R, K, P * N>(s.Cb, f.C_K, s.dwn);
-        acc_mix<R, K, P * N>(acc.dC, s.w, s.Cb);
+        // gradients w.r.t. the mixed matrices of this step
+        gstore_mat<R, N, N>(g.bar_As + (tb + B) * N * N, s.Ab);
+        gstore_mat<R, P, N>(g.bar_Cs + tb * P * N, s.Cb);
     }
     {
-        gload_or_zero<R, N * N>(g.g_As, (long)b * N * N, s.Ab);
-        gload<R, K>(f.alpha + (long)b * K, s.w);
-        basis_dots<R, K, N * N>(s.Ab, f.A_K, s.da);
-        KW_FOR(k, K) s.da[k] += s.dwn[k];
-        KW_SYNC();
-        gstore<R, K>(g.d_alpha + (long)b * K, s.da);
-        acc_mix<R, K, N * N>(acc.dA, s.w, s.Ab);
+        // A_0 only feeds the returned mat_As[0]
+        gload_mat_or_zero<R, N, N>(g.g_As, (long)b * N * N, s.Ab);
+        gstore_mat<R, N, N>(g.bar_As + (long)b * N * N, s.Ab);
     }
     gstore<R, N>(g.d_m_in + (long)b * N, s.mpb);
-    gstore<R, N * N>(g.d_P_in + (long)b * N * N, s.Ppb);
+    gstore_mat<R, N, N>(g.d_P_in + (long)b * N * N, s.Ppb);
 }
 
 // ---------------------------------------------------------------------------
@@ -559,15 +756,17 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b,
 // ---------------------------------------------------------------------------
 template <typename R, int N, int P>
 struct SmoothScratch {
-    R LR[P * P], ms[N], Ps[N * N], C[P * N], m[N], Pf[N * N], mn[N], Pn[N * N], An[N * N];
-    R Pi[N * N], L[N * N], Li[N * N], W[N * N], J[N * N], d[N], D[N * N], T1[N * N];
+    static constexpr int NN = msize(N, N), PN = msize(P, N), PP = msize(P, P);
+    R LR[PP], ms[N], Ps[NN], C[PN], m[N], Pf[NN], mn[N], Pn[NN], An[NN];
+    R Pi[NN], L[NN], Li[NN], W[NN], J[NN], d[N], D[NN], T1[NN];
     R z[N], ar[P], e[N], eo[P];
 };
 template <typename R, int N, int P>
 struct SmoothBwdScratch : SmoothScratch<R, N, P> {
-    R ms1[N], Ps1[N * N], msb[N], Psb[N * N], Cb[P * N], zb[N], ab[P], Lb[N * N], X[N * N],
-        Y[N * N], Pfb[N * N], Jb[N * N], db[N], Db[N * N], Wb[N * N], Anb[N * N], Pib[N * N],
-        Pnb[N * N];
+    using B0 = SmoothScratch<R, N, P>;
+    R ms1[N], Ps1[B0::NN], msb[N], Psb[B0::NN], Cb[B0::PN], zb[N], ab[P], Lb[B0::NN], X[B0::NN],
+        Y[B0::NN], Pfb[B0::NN], Jb[B0::NN], db[N], Db[B0::NN], Wb[B0::NN], Anb[B0::NN],
+        Pib[B0::NN], Pnb[B0::NN];
 };
 
 template <typename R, int N, int P>
@@ -575,7 +774,7 @@ KV_HD bool smooth_emit(const SmoothFwdArgs<R>& g, long tb, SmoothScratch<R, N, P
     bool ok = true;
     vcopy<R, N>(s.ms, s.z);
     if (g.eps_s) {
-        vcopy<R, N * N>(s.Ps, s.T1);
+        vcopy<R, msize(N, N)>(s.Ps, s.T1);
         ok = cholesky<R, N>(s.T1, s.L);
         gload<R, N>(g.eps_s + tb * N, s.e);
         gemv<R, N, N, false, 1>(s.L, s.e, s.z);
@@ -590,52 +789,53 @@ KV_HD bool smooth_emit(const SmoothFwdArgs<R>& g, long tb, SmoothScratch<R, N, P
     return ok;
 }
 
-// J = Pf An^T Pn^-1, d = ms_next - mn, D = Ps_next - Pn; (ms, Ps) hold step t+1 on entry.
+// J = Pf An^T Pn^-1, d = ms_next - mn, D = Ps_next - Pn
 template <typename R, int N, int P>
 KV_HD bool smooth_gain(SmoothScratch<R, N, P>& s, const R* ms_next, const R* Ps_next) {
-    vcopy<R, N * N>(s.Pn, s.T1);
+    constexpr int NN = msize(N, N);
+    vcopy<R, NN>(s.Pn, s.T1);
     const bool ok = spd_inverse<R, N>(s.T1, s.Pi, s.L, s.Li);
     gemm<R, N, N, N, true, false, 0>(s.An, s.Pi, s.W);
     gemm<R, N, N, N, false, false, 0>(s.Pf, s.W, s.J);
     axpby<R, N>(R(1), ms_next, R(-1), s.mn, s.d);
-    axpby<R, N * N>(R(1), Ps_next, R(-1), s.Pn, s.D);
+    axpby<R, NN>(R(1), Ps_next, R(-1), s.Pn, s.D);
     return ok;
 }
 
 template <typename R, int N, int P>
 KV_HD void smooth_forward_sequence(const SmoothFwdArgs<R>& g, int b, SmoothScratch<R, N, P>& s) {
+    constexpr int NN = msize(N, N);
     const long B = g.B;
     const int T = g.T;
-    if (g.eps_o) {
-        gload<R, P * P>(g.LR, s.LR);
-    }
+    clear_scratch<SmoothScratch<R, N, P>, R>(s);
+    if (g.eps_o) gload_mat<R, P, P>(g.LR, s.LR);
     int st = 0;
     {
         const long tb = (long)(T - 1) * B + b;
         gload<R, N>(g.m + tb * N, s.ms);
-        gload<R, N * N>(g.Pf + tb * N * N, s.Ps);
-        gload<R, P * N>(g.Cs + (tb + B) * P * N, s.C);
+        gload_mat<R, N, N>(g.Pf + tb * N * N, s.Ps);
+        gload_mat<R, P, N>(g.Cs + (tb + B) * P * N, s.C);
         gstore<R, N>(g.ms + tb * N, s.ms);
-        gstore<R, N * N>(g.Ps + tb * N * N, s.Ps);
+        gstore_mat<R, N, N>(g.Ps + tb * N * N, s.Ps);
         if (!smooth_emit<R, N, P>(g, tb, s)) st |= ST_NONPD_SMOOTHED;
     }
     for (int t = T - 2; t >= 0; --t) {
         const long tb = (long)t * B + b;
         gload<R, N>(g.m + tb * N, s.m);
-        gload<R, N * N>(g.Pf + tb * N * N, s.Pf);
+        gload_mat<R, N, N>(g.Pf + tb * N * N, s.Pf);
         gload<R, N>(g.mn + tb * N, s.mn);
-        gload<R, N * N>(g.Pn + tb * N * N, s.Pn);
-        gload<R, N * N>(g.As + (tb + B) * N * N, s.An);
-        gload<R, P * N>(g.Cs + tb * P * N, s.C);
+        gload_mat<R, N, N>(g.Pn + tb * N * N, s.Pn);
+        gload_mat<R, N, N>(g.As + (tb + B) * N * N, s.An);
+        gload_mat<R, P, N>(g.Cs + tb * P * N, s.C);
         if (!smooth_gain<R, N, P>(s, s.ms, s.Ps)) st |= ST_NONPD_PREDICTED;
         vcopy<R, N>(s.m, s.ms);
         gemv<R, N, N, false, 1>(s.J, s.d, s.ms);
         gemm<R, N, N, N, false, false, 0>(s.J, s.D, s.T1);
-        vcopy<R, N * N>(s.Pf, s.Ps);
+        vcopy<R, NN>(s.Pf, s.Ps);
         gemm<R, N, N, N, false, true, 1>(s.T1, s.J, s.Ps);
         if (g.symmetrize) symmetrize_inplace<R, N>(s.Ps);
         gstore<R, N>(g.ms + tb * N, s.ms);
-        gstore<R, N * N>(g.Ps + tb * N * N, s.Ps);
+        gstore_mat<R, N, N>(g.Ps + tb * N * N, s.Ps);
         if (!smooth_emit<R, N, P>(g, tb, s)) st |= ST_NONPD_SMOOTHED;
     }
     raise_status(g.status, st);
@@ -646,13 +846,14 @@ KV_HD void smooth_forward_sequence(const SmoothFwdArgs<R>& g, int b, SmoothScrat
 template <typename R, int N, int P>
 KV_HD void smooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, SmoothBwdScratch<R, N, P>& s,
                                Acc<R, P * P>& acc_LR) {
+    constexpr int NN = msize(N, N);
     const SmoothFwdArgs<R>& f = g.f;
     gload_or_zero<R, N>(g.g_zs, tb * N, s.zb);
     gload_or_zero<R, P>(g.g_ares, tb * P, s.ab);
-    vzero<R, P * N>(s.Cb);
+    vzero<R, msize(P, N)>(s.Cb);
     if (!g.g_ares && !g.g_zs) return;
     if (f.eps_s) {
-        vcopy<R, N * N>(s.Ps, s.T1);
+        vcopy<R, NN>(s.Ps, s.T1);
         cholesky<R, N>(s.T1, s.L);
         gload<R, N>(f.eps_s + tb * N, s.e);
     }
@@ -663,15 +864,15 @@ KV_HD void smooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, SmoothBwdScra
         gemv<R, N, P, true, 1>(s.C, s.ab, s.zb);
         if (f.eps_o) {
             gload<R, P>(f.eps_o + tb * P, s.eo);
-            vzero<R, P * P>(s.X);
+            vzero<R, msize(P, P)>(s.X);
             outer_add<R, P, P>(R(1), s.ab, s.eo, s.X);
-            acc_LR.axpy(R(1), s.X);
+            acc_LR.template axpy<P>(R(1), s.X);
         }
     }
     vadd<R, N>(s.zb, s.msb);
     if (f.eps_s) {
         tri_lower_inverse<R, N>(s.L, s.Li);
-        vzero<R, N * N>(s.Lb);
+        vzero<R, NN>(s.Lb);
         outer_add<R, N, N>(R(1), s.zb, s.e, s.Lb);
         cholesky_adjoint_add<R, N>(s.L, s.Li, s.Lb, s.X, s.Y, s.Psb);
     }
@@ -679,13 +880,13 @@ KV_HD void smooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, SmoothBwdScra
 
 template <typename R, int N, int P>
 KV_HD void smooth_backward_sequence(const SmoothBwdArgs<R>& g, int b,
-                                    SmoothBwdScratch<R, N, P>& s,
-                                    Acc<R, P * P>& acc_LR) {
+                                    SmoothBwdScratch<R, N, P>& s, Acc<R, P * P>& acc_LR) {
+    constexpr int NN = msize(N, N);
     const SmoothFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
-    vzero<R, N>(s.msb);
-    vzero<R, N * N>(s.Psb);
+    clear_scratch<SmoothBwdScratch<R, N, P>, R>(s);
+    if (f.eps_o) gload_mat<R, P, P>(f.LR, s.LR);
     gstore_zero<R, N * N>(g.d_As + (long)b * N * N);
     gstore_zero<R, N * N>(g.d_As + ((long)T * B + b) * N * N);
     gstore_zero<R, P * N>(g.d_Cs + ((long)(T - 1) * B + b) * P * N);
@@ -694,28 +895,28 @@ KV_HD void smooth_backward_sequence(const SmoothBwdArgs<R>& g, int b,
     for (int t = 0; t < T - 1; ++t) {
         const long tb = (long)t * B + b;
         gload<R, N>(f.m + tb * N, s.m);
-        gload<R, N * N>(f.Pf + tb * N * N, s.Pf);
+        gload_mat<R, N, N>(f.Pf + tb * N * N, s.Pf);
         gload<R, N>(f.mn + tb * N, s.mn);
-        gload<R, N * N>(f.Pn + tb * N * N, s.Pn);
-        gload<R, N * N>(f.As + (tb + B) * N * N, s.An);
-        gload<R, P * N>(f.Cs + tb * P * N, s.C);
+        gload_mat<R, N, N>(f.Pn + tb * N * N, s.Pn);
+        gload_mat<R, N, N>(f.As + (tb + B) * N * N, s.An);
+        gload_mat<R, P, N>(f.Cs + tb * P * N, s.C);
         gload<R, N>(f.ms + (tb + B) * N, s.ms1);
-        gload<R, N * N>(f.Ps + (tb + B) * N * N, s.Ps1);
+        gload_mat<R, N, N>(f.Ps + (tb + B) * N * N, s.Ps1);
         gload<R, N>(f.ms + tb * N, s.ms);
-        gload<R, N * N>(f.Ps + tb * N * N, s.Ps);
+        gload_mat<R, N, N>(f.Ps + tb * N * N, s.Ps);
         gload_add<R, N>(g.g_ms, tb * N, s.msb);
-        gload_add<R, N * N>(g.g_Ps, tb * N * N, s.Psb);
+        gload_mat_add<R, N, N>(g.g_Ps, tb * N * N, s.Psb);
         smooth_emit_adjoint<R, N, P>(g, tb, s, acc_LR);
-        gstore<R, P * N>(g.d_Cs + tb * P * N, s.Cb);
+        gstore_mat<R, P, N>(g.d_Cs + tb * P * N, s.Cb);
         if (t < g.burn_in) {
             vzero<R, N>(s.msb);
-            vzero<R, N * N>(s.Psb);
+            vzero<R, NN>(s.Psb);
         }
         smooth_gain<R, N, P>(s, s.ms1, s.Ps1);
         if (f.symmetrize) symmetrize_inplace<R, N>(s.Psb);
         gstore<R, N>(g.d_m + tb * N, s.msb);
-        vcopy<R, N * N>(s.Psb, s.Pfb);
-        vzero<R, N * N>(s.Jb);
+        vcopy<R, NN>(s.Psb, s.Pfb);
+        vzero<R, NN>(s.Jb);
         outer_add<R, N, N>(R(1), s.msb, s.d, s.Jb);
         gemm<R, N, N, N, false, true, 0>(s.J, s.D, s.T1);
         gemm<R, N, N, N, false, false, 1>(s.Psb, s.T1, s.Jb);
@@ -730,25 +931,25 @@ KV_HD void smooth_backward_sequence(const SmoothBwdArgs<R>& g, int b,
         gemm<R, N, N, N, false, false, 0>(s.An, s.Wb, s.Pib);
         gemm<R, N, N, N, true, false, 0>(s.Pi, s.Pib, s.T1);
         gemm<R, N, N, N, false, true, 0>(s.T1, s.Pi, s.Pnb);
-        axpby<R, N * N>(R(-1), s.Pnb, R(-1), s.Db, s.Pnb);
-        gstore<R, N * N>(g.d_P + tb * N * N, s.Pfb);
+        axpby<R, NN>(R(-1), s.Pnb, R(-1), s.Db, s.Pnb);
+        gstore_mat<R, N, N>(g.d_P + tb * N * N, s.Pfb);
         KW_FOR(i, N) g.d_mn[tb * N + i] = -s.db[i];
-        gstore<R, N * N>(g.d_Pn + tb * N * N, s.Pnb);
-        gstore<R, N * N>(g.d_As + (tb + B) * N * N, s.Anb);
+        gstore_mat<R, N, N>(g.d_Pn + tb * N * N, s.Pnb);
+        gstore_mat<R, N, N>(g.d_As + (tb + B) * N * N, s.Anb);
         vcopy<R, N>(s.db, s.msb);
-        vcopy<R, N * N>(s.Db, s.Psb);
+        vcopy<R, NN>(s.Db, s.Psb);
     }
     {
         const long tb = (long)(T - 1) * B + b;
         gload<R, N>(f.ms + tb * N, s.ms);
-        gload<R, N * N>(f.Ps + tb * N * N, s.Ps);
-        gload<R, P * N>(f.Cs + (tb + B) * P * N, s.C);
+        gload_mat<R, N, N>(f.Ps + tb * N * N, s.Ps);
+        gload_mat<R, P, N>(f.Cs + (tb + B) * P * N, s.C);
         gload_add<R, N>(g.g_ms, tb * N, s.msb);
-        gload_add<R, N * N>(g.g_Ps, tb * N * N, s.Psb);
+        gload_mat_add<R, N, N>(g.g_Ps, tb * N * N, s.Psb);
         smooth_emit_adjoint<R, N, P>(g, tb, s, acc_LR);
-        gstore<R, P * N>(g.d_Cs + (tb + B) * P * N, s.Cb);
+        gstore_mat<R, P, N>(g.d_Cs + (tb + B) * P * N, s.Cb);
         gstore<R, N>(g.d_m + tb * N, s.msb);
-        gstore<R, N * N>(g.d_P + tb * N * N, s.Psb);
+        gstore_mat<R, N, N>(g.d_P + tb * N * N, s.Psb);
     }
 }
 
@@ -759,21 +960,23 @@ KV_HD void smooth_backward_sequence(const SmoothBwdArgs<R>& g, int b,
 // ---------------------------------------------------------------------------
 template <typename R, int N, int P>
 struct ElboScratch {
-    R Q[N * N], LQ[N * N], LiQ[N * N], Rm[P * P], LRm[P * P], LiR[P * P];
-    R P0[N * N], L0[N * N], Li0[N * N], m0[N];
-    R Ps[N * N], L[N * N], Li[N * N], z[N], zp[N], e[N], C[P * N], A[N * N], r[N], ro[P], y[N];
-    R T1[N * N];
+    static constexpr int NN = msize(N, N), PN = msize(P, N), PP = msize(P, P);
+    R Q[NN], LQ[NN], LiQ[NN], Rm[PP], LRm[PP], LiR[PP];
+    R P0[NN], L0[NN], Li0[NN], m0[N];
+    R Ps[NN], L[NN], Li[NN], z[N], zp[N], e[N], C[PN], A[NN], r[N], ro[P], y[N];
+    R T1[NN];
 };
 template <typename R, int N, int P>
 struct ElboBwdScratch : ElboScratch<R, N, P> {
-    R zn_back[N], zb[N], Ab[N * N], Cb[P * N], Lb[N * N], X[N * N], Y[N * N], Psb[N * N],
-        SiQ[N * N], SiR[P * P], Si0[N * N], G1[N * N], G2[P * P];
+    using B0 = ElboScratch<R, N, P>;
+    R zn_back[N], zb[N], Ab[B0::NN], Cb[B0::PN], Lb[B0::NN], X[B0::NN], Y[B0::NN], Psb[B0::NN],
+        SiQ[B0::NN], SiR[B0::PP], Si0[B0::NN], G1[B0::NN], G2[B0::PP];
 };
 
 // s.z = ms + chol(Ps) eps at pair tb; leaves L in s.L, eps in s.e
 template <typename R, int N, int P>
 KV_HD bool elbo_sample(const ElboFwdArgs<R>& g, long tb, ElboScratch<R, N, P>& s) {
-    gload<R, N * N>(g.Ps + tb * N * N, s.T1);
+    gload_mat<R, N, N>(g.Ps + tb * N * N, s.T1);
     gload<R, N>(g.ms + tb * N, s.z);
     gload<R, N>(g.eps + tb * N, s.e);
     const bool ok = cholesky<R, N>(s.T1, s.L);
@@ -792,17 +995,18 @@ KV_HD R whiten(const R* Li, R* r, R* y) {
 
 template <typename R, int N, int P>
 KV_HD int elbo_prepare(const ElboFwdArgs<R>& g, ElboScratch<R, N, P>& s) {
+    constexpr int NN = msize(N, N), PP = msize(P, P);
     int st = 0;
-    gload<R, N * N>(g.Q, s.Q);
-    vcopy<R, N * N>(s.Q, s.T1);
+    gload_mat<R, N, N>(g.Q, s.Q);
+    vcopy<R, NN>(s.Q, s.T1);
     if (!cholesky<R, N>(s.T1, s.LQ)) st |= ST_NONPD_NOISE;
     tri_lower_inverse<R, N>(s.LQ, s.LiQ);
-    gload<R, P * P>(g.Rm, s.Rm);
-    vcopy<R, P * P>(s.Rm, s.T1);
+    gload_mat<R, P, P>(g.Rm, s.Rm);
+    vcopy<R, PP>(s.Rm, s.T1);
     if (!cholesky<R, P>(s.T1, s.LRm)) st |= ST_NONPD_NOISE;
     tri_lower_inverse<R, P>(s.LRm, s.LiR);
-    gload<R, N * N>(g.P0, s.P0);
-    vcopy<R, N * N>(s.P0, s.T1);
+    gload_mat<R, N, N>(g.P0, s.P0);
+    vcopy<R, NN>(s.P0, s.T1);
     if (!cholesky<R, N>(s.T1, s.L0)) st |= ST_NONPD_NOISE;
     tri_lower_inverse<R, N>(s.L0, s.Li0);
     gload<R, N>(g.m0, s.m0);
@@ -812,6 +1016,7 @@ KV_HD int elbo_prepare(const ElboFwdArgs<R>& g, ElboScratch<R, N, P>& s) {
 template <typename R, int N, int P>
 KV_HD void elbo_forward_sequence(const ElboFwdArgs<R>& g, int b, ElboScratch<R, N, P>& s) {
     const long B = g.B;
+    clear_scratch<ElboScratch<R, N, P>, R>(s);
     int st = elbo_prepare<R, N, P>(g, s);
     const R hlQ = half_logdet<R, N>(s.LQ), hlR = half_logdet<R, P>(s.LRm),
             hl0 = half_logdet<R, N>(s.L0);
@@ -820,7 +1025,7 @@ KV_HD void elbo_forward_sequence(const ElboFwdArgs<R>& g, int b, ElboScratch<R, 
         if (!elbo_sample<R, N, P>(g, tb, s)) st |= ST_NONPD_SMOOTHED;
         if (g.z) gstore<R, N>(g.z + tb * N, s.z);
         // observation
-        gload<R, P * N>(g.Cs + tb * P * N, s.C);
+        gload_mat<R, P, N>(g.Cs + tb * P * N, s.C);
         gload<R, P>(g.a + tb * P, s.ro);
         gemv<R, P, N, false, 2>(s.C, s.z, s.ro);
         const R qo = whiten<R, P>(s.LiR, s.ro, s.y);
@@ -831,7 +1036,7 @@ KV_HD void elbo_forward_sequence(const ElboFwdArgs<R>& g, int b, ElboScratch<R, 
             qt = whiten<R, N>(s.Li0, s.r, s.y);
             hlt = hl0;
         } else {
-            gload<R, N * N>(g.As + tb * N * N, s.A);
+            gload_mat<R, N, N>(g.As + tb * N * N, s.A);
             vcopy<R, N>(s.z, s.r);
             gemv<R, N, N, false, 2>(s.A, s.zp, s.r);
             qt = whiten<R, N>(s.LiQ, s.r, s.y);
@@ -873,17 +1078,22 @@ struct ElboGradAcc {
 // G (D x D work buffer) = 1/2 (u u^T - Si); acc += w * G
 template <typename R, int D>
 KV_HD void cov_grad(R w, const R* u, const R* Si, R* G, Acc<R, D * D>& acc) {
-    KW_FOR(e, D * D) G[e] = R(0.5) * (u[e / D] * u[e % D] - Si[e]);
+    KW_FOR(e, D * D) {
+        const int q = pad_index<D>(e);
+        G[q] = R(0.5) * (u[e / D] * u[e % D] - Si[q]);
+    }
     KW_SYNC();
-    acc.axpy(w, G);
+    acc.template axpy<D>(w, G);
 }
 
 template <typename R, int N, int P>
 KV_HD void elbo_backward_sequence(const ElboBwdArgs<R>& g, int b, ElboBwdScratch<R, N, P>& s,
                                   ElboGradAcc<R, N, P>& acc) {
+    constexpr int NN = msize(N, N), PN = msize(P, N);
     const ElboFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
+    clear_scratch<ElboBwdScratch<R, N, P>, R>(s);
     elbo_prepare<R, N, P>(f, s);
     gemm<R, N, N, N, true, false, 0>(s.LiQ, s.LiQ, s.SiQ);
     gemm<R, P, P, P, true, false, 0>(s.LiR, s.LiR, s.SiR);
@@ -899,66 +1109,83 @@ KV_HD void elbo_backward_sequence(const ElboBwdArgs<R>& g, int b, ElboBwdScratch
         elbo_sample<R, N, P>(f, tb, s);  // s.z, s.L, s.e
         vcopy<R, N>(s.zn_back, s.zb);
         // observation term
-        gload<R, P * N>(f.Cs + tb * P * N, s.C);
+        gload_mat<R, P, N>(f.Cs + tb * P * N, s.C);
         gload<R, P>(f.a + tb * P, s.ro);
         gemv<R, P, N, false, 2>(s.C, s.z, s.ro);
         whiten<R, P>(s.LiR, s.ro, s.y);  // s.ro = R^-1 r
         KW_FOR(i, P) g.d_a[tb * P + i] = -wo * s.ro[i];
-        vzero<R, P * N>(s.Cb);
+        vzero<R, PN>(s.Cb);
         outer_add<R, P, N>(wo, s.ro, s.z, s.Cb);
-        gstore<R, P * N>(g.d_Cs + tb * P * N, s.Cb);
-        KW_FOR(j, N) {
-            R acc_j = R(0);
-            for (int i = 0; i < P; ++i) acc_j += s.C[i * N + j] * s.ro[i];
-            s.zb[j] += wo * acc_j;
-        }
-        KW_SYNC();
+        gstore_mat<R, P, N>(g.d_Cs + tb * P * N, s.Cb);
+        gemv<R, N, P, true, 0>(s.C, s.ro, s.y);  // C^T u
+        axpby<R, N>(R(1), s.zb, wo, s.y, s.zb);
         cov_grad<R, P>(wo, s.ro, s.SiR, s.G2, acc.dR);
         // transition term of this pair
-        vzero<R, N * N>(s.Ab);
+        vzero<R, NN>(s.Ab);
         if (t == 0) {
             axpby<R, N>(R(1), s.z, R(-1), s.m0, s.r);
             whiten<R, N>(s.Li0, s.r, s.y);
-            acc.dm0.axpy(wt, s.r);
+            acc.dm0.template axpy<1>(wt, s.r);
             cov_grad<R, N>(wt, s.r, s.Si0, s.G1, acc.dP0);
-            vzero<R, N>(s.zn_back);
         } else {
             // previous sample z_{t-1}: recompute into s.zp without disturbing s.L / s.e
             {
                 const long tp = tb - B;
-                gload<R, N * N>(f.Ps + tp * N * N, s.T1);
+                gload_mat<R, N, N>(f.Ps + tp * N * N, s.T1);
                 gload<R, N>(f.ms + tp * N, s.zp);
                 gload<R, N>(f.eps + tp * N, s.y);
                 cholesky<R, N>(s.T1, s.X);
                 gemv<R, N, N, false, 1>(s.X, s.y, s.zp);
             }
-            gload<R, N * N>(f.As + tb * N * N, s.A);
+            gload_mat<R, N, N>(f.As + tb * N * N, s.A);
             vcopy<R, N>(s.z, s.r);
             gemv<R, N, N, false, 2>(s.A, s.zp, s.r);
             whiten<R, N>(s.LiQ, s.r, s.y);  // s.r = Q^-1 r
             outer_add<R, N, N>(wt, s.r, s.zp, s.Ab);
             cov_grad<R, N>(wt, s.r, s.SiQ, s.G1, acc.dQ);
             // contribution to z_{t-1}: w_t A_t^T u_t, consumed by the next iteration
-            KW_FOR(j, N) {
-                R acc_j = R(0);
-                for (int i = 0; i < N; ++i) acc_j += s.A[i * N + j] * s.r[i];
-                s.zn_back[j] = wt * acc_j;
-            }
-            KW_SYNC();
+            gemv<R, N, N, true, 0>(s.A, s.r, s.zn_back);
+            vscale<R, N>(wt, s.zn_back);
         }
-        KW_FOR(i, N) s.zb[i] -= wt * s.r[i];
-        KW_SYNC();
-        gstore<R, N * N>(g.d_As + tb * N * N, s.Ab);
+        axpby<R, N>(R(1), s.zb, -wt, s.r, s.zb);
+        gstore_mat<R, N, N>(g.d_As + tb * N * N, s.Ab);
         gstore<R, N>(g.d_ms + tb * N, s.zb);
         // z = ms + L eps; posterior term: -wp sum log diag L
-        vzero<R, N * N>(s.Lb);
+        vzero<R, NN>(s.Lb);
         outer_add<R, N, N>(R(1), s.zb, s.e, s.Lb);
-        KW_FOR(i, N) s.Lb[i * N + i] -= wp / s.L[i * N + i];
+        KW_FOR(i, N) s.Lb[i * ld(N) + i] -= wp / s.L[i * ld(N) + i];
         KW_SYNC();
         tri_lower_inverse<R, N>(s.L, s.Li);
-        vzero<R, N * N>(s.Psb);
+        vzero<R, NN>(s.Psb);
         cholesky_adjoint_add<R, N>(s.L, s.Li, s.Lb, s.X, s.Y, s.Psb);
-        gstore<R, N * N>(g.d_Ps + tb * N * N, s.Psb);
+        gstore_mat<R, N, N>(g.d_Ps + tb * N * N, s.Psb);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Mixing adjoint (second pass of the filter backward of this variant).
+// For every row r = (t, b) of the (T+1)*B rows:
+//   d_alpha[r][k] = <bar_As[r], A^k> + <bar_Cs[r], C^k>
+//   d_A_K[k] += alpha[r][k] * bar_As[r],   d_C_K[k] += alpha[r][k] * bar_Cs[r]
+// The device kernels are in wave_kernels.hip; this single-thread form defines
+// the arithmetic and serves the host build.
+// ---------------------------------------------------------------------------
+template <typename R, int N, int P, int K>
+inline void mix_adjoint_host(long rows, const R* alpha, const R* bar_As, const R* bar_Cs,
+                             const R* A_K, const R* C_K, R* d_alpha, R* d_A_K, R* d_C_K) {
+    constexpr int LA = N * N, LC = P * N;
+    for (int i = 0; i < K * LA; ++i) d_A_K[i] = R(0);
+    for (int i = 0; i < K * LC; ++i) d_C_K[i] = R(0);
+    for (long r = 0; r < rows; ++r) {
+        for (int k = 0; k < K; ++k) {
+            R acc = R(0);
+            for (int e = 0; e < LA; ++e) acc += bar_As[r * LA + e] * A_K[k * LA + e];
+            for (int e = 0; e < LC; ++e) acc += bar_Cs[r * LC + e] * C_K[k * LC + e];
+            d_alpha[r * K + k] = acc;
+            const R w = alpha[r * K + k];
+            for (int e = 0; e < LA; ++e) d_A_K[k * LA + e] += w * bar_As[r * LA + e];
+            for (int e = 0; e < LC; ++e) d_C_K[k * LC + e] += w * bar_Cs[r * LC + e];
+        }
     }
 }
 

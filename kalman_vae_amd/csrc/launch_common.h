@@ -145,6 +145,8 @@ FilterBwdArgs<R> make_args(const kvae_dims* d, const kvae_filter_bwd* io, void* 
     g.d_m_in = (R*)io->d_m_in;
     g.d_P_in = (R*)io->d_P_in;
     g.partial = (R*)ws;
+    g.bar_As = nullptr;
+    g.bar_Cs = nullptr;
     return g;
 }
 

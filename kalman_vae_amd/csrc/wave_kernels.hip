@@ -27,7 +27,81 @@ __global__ void __launch_bounds__(64) wave_filter_backward_kernel(FilterBwdArgs<
     wave::FilterGradAcc<R, N, P, K> acc;
     acc.zero();
     wave::filter_backward_sequence<R, N, P, K>(g, blockIdx.x, s, acc);
-    acc.store(g.partial + (long)blockIdx.x * FilterParamGrads<N, P, K>::LEN);
+    acc.store(g.partial + (long)blockIdx.x * wave::FilterGradAcc<R, N, P, K>::LEN);
+}
+
+// ---- mixing adjoint, second pass of the filter backward ------------------------
+// (arithmetic defined by wave::mix_adjoint_host)
+constexpr int MIX_ROWS_PER_CHUNK = 1024;
+
+// d_alpha[r][k] = <bar_As[r], A^k> + <bar_Cs[r], C^k>.  One wavefront per row
+// (grid-stride), bases staged once per workgroup in LDS.
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(256) mix_dalpha_kernel(long rows, const R* bar_As,
+                                                        const R* bar_Cs, const R* A_K,
+                                                        const R* C_K, R* d_alpha) {
+    constexpr int LA = N * N, LC = P * N;
+    __shared__ R bases[K * (LA + LC)];
+    for (int i = threadIdx.x; i < K * LA; i += 256) bases[i] = A_K[i];
+    for (int i = threadIdx.x; i < K * LC; i += 256) bases[K * LA + i] = C_K[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long r = wave0; r < rows; r += nwaves) {
+        R acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = R(0);
+        for (int e = lane; e < LA; e += 64) {
+            const R x = bar_As[r * LA + e];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += x * bases[k * LA + e];
+        }
+        for (int e = lane; e < LC; e += 64) {
+            const R x = bar_Cs[r * LC + e];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += x * bases[K * LA + k * LC + e];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const R v = wave_sum<R>(acc[k]);
+            if (lane == 0) d_alpha[r * K + k] = v;
+        }
+    }
+}
+
+// partial[chunk][k*LA + e] = sum_{r in chunk} alpha[r][k] bar_As[r][e] (and the
+// same for C behind it).  Thread = one column, workgroup = 256 columns x one
+// chunk of rows; every load of the bar_* stream is a fully coalesced row piece.
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(256) mix_dbasis_kernel(long rows, const R* alpha,
+                                                        const R* bar_As, const R* bar_Cs,
+                                                        R* partial) {
+    constexpr int LA = N * N, LC = P * N;
+    const int c = blockIdx.x * 256 + threadIdx.x;  // column of [bar_As | bar_Cs]
+    const long r0 = (long)blockIdx.y * MIX_ROWS_PER_CHUNK;
+    const long r1 = r0 + MIX_ROWS_PER_CHUNK < rows ? r0 + MIX_ROWS_PER_CHUNK : rows;
+    if (c >= LA + LC) return;
+    const bool isA = c < LA;
+    const R* src = isA ? bar_As + c : bar_Cs + (c - LA);
+    const long stride = isA ? LA : LC;
+    R acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = R(0);
+    for (long r = r0; r < r1; ++r) {
+        const R x = src[r * stride];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += alpha[r * K + k] * x;
+    }
+    R* out = partial + (long)blockIdx.y * (K * (LA + LC));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (isA) {
+            out[k * LA + c] = acc[k];
+        } else {
+            out[K * LA + k * LC + (c - LA)] = acc[k];
+        }
+    }
 }
 
 template <typename R, int N, int P>
@@ -78,11 +152,36 @@ int run_wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void
     if constexpr (sizeof(wave::FilterBwdScratch<R, N, P, K>) > LDS_LIMIT) {
         return KVAE_E_UNSUPPORTED;
     } else {
-        using PG = FilterParamGrads<N, P, K>;
-        if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
-        FilterBwdArgs<R> g = make_args<R>(d, io, ws);
+        constexpr int LA = N * N, LC = P * N, QR = N * N + P * P;
+        const long rows = (long)(d->T + 1) * d->B;
+        const long chunks = (rows + MIX_ROWS_PER_CHUNK - 1) / MIX_ROWS_PER_CHUNK;
+        const size_t need = ((size_t)rows * (LA + LC) + (size_t)d->B * QR +
+                             (size_t)chunks * K * (LA + LC)) * sizeof(R);
+        if (ws_bytes < need) return KVAE_E_WORKSPACE;
+        R* bar_As = (R*)ws;
+        R* bar_Cs = bar_As + rows * LA;
+        R* qr_partial = bar_Cs + rows * LC;
+        R* mix_partial = qr_partial + (long)d->B * QR;
+        FilterBwdArgs<R> g = make_args<R>(d, io, qr_partial);
+        g.bar_As = bar_As;
+        g.bar_Cs = bar_Cs;
         hipLaunchKernelGGL((wave_filter_backward_kernel<R, N, P, K>), dim3(d->B), dim3(64), 0, s, g);
-        reduce_filter_grads<R, N, P, K>(io, ws, d->B, s);
+        {   // d_Q, d_R: sum the per-sequence rows
+            void* outs[2] = {io->d_Q, io->d_R};
+            const int begin[3] = {0, N * N, QR};
+            launch_reduce<R>(qr_partial, d->B, QR, 2, outs, begin, s);
+        }
+        const long dalpha_blocks = rows / 4 + 1 < 2048 ? rows / 4 + 1 : 2048;
+        hipLaunchKernelGGL((mix_dalpha_kernel<R, N, P, K>), dim3(dalpha_blocks), dim3(256), 0, s,
+                           rows, (const R*)bar_As, (const R*)bar_Cs, g.f.A_K, g.f.C_K, g.d_alpha);
+        hipLaunchKernelGGL((mix_dbasis_kernel<R, N, P, K>),
+                           dim3((LA + LC + 255) / 256, chunks), dim3(256), 0, s, rows, g.f.alpha,
+                           (const R*)bar_As, (const R*)bar_Cs, mix_partial);
+        {   // d_A_K, d_C_K: sum the per-chunk rows
+            void* outs[2] = {io->d_A_K, io->d_C_K};
+            const int begin[3] = {0, K * LA, K * (LA + LC)};
+            launch_reduce<R>(mix_partial, chunks, K * (LA + LC), 2, outs, begin, s);
+        }
         return launch_status();
     }
 }
@@ -172,8 +271,12 @@ size_t wave_workspace_bytes(const kvae_dims* d, int op) {
     const size_t el = d->dtype == KVAE_F32 ? 4 : 8;
     const long n = d->n, p = d->p, K = d->K;
     switch (op) {
-        case KVAE_OP_FILTER_BWD:
-            return (size_t)d->B * (K * n * n + K * p * n + n * n + p * p) * el;
+        case KVAE_OP_FILTER_BWD: {
+            const size_t rows = (size_t)(d->T + 1) * d->B;
+            const size_t chunks = (rows + MIX_ROWS_PER_CHUNK - 1) / MIX_ROWS_PER_CHUNK;
+            return (rows * (n * n + p * n) + (size_t)d->B * (n * n + p * p) +
+                    chunks * K * (n * n + p * n)) * el;
+        }
         case KVAE_OP_SMOOTH_BWD:
             return (size_t)d->B * (p * p) * el;
         case KVAE_OP_ELBO_BWD:

@@ -79,6 +79,7 @@ int filter_bwd(const kvae_dims* d, const kvae_filter_bwd* io) {
     g.g_As = (const R*)io->g_mat_As; g.g_Cs = (const R*)io->g_mat_Cs;
     g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha;
     g.d_m_in = (R*)io->d_m_in; g.d_P_in = (R*)io->d_P_in; g.partial = nullptr;
+    g.bar_As = nullptr; g.bar_Cs = nullptr;
     std::vector<R> acc(PG::LEN, R(0));
     for (int b = 0; b < d->B; ++b) filter_backward_sequence<R, N, P, K>(g, b, acc.data());
     put<R>(io->d_A_K, acc.data() + PG::OFF_A, K * N * N);
@@ -149,6 +150,7 @@ FilterBwdArgs<R> mkb(const kvae_dims* d, const kvae_filter_bwd* io) {
     g.g_As = (const R*)io->g_mat_As; g.g_Cs = (const R*)io->g_mat_Cs;
     g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha;
     g.d_m_in = (R*)io->d_m_in; g.d_P_in = (R*)io->d_P_in; g.partial = nullptr;
+    g.bar_As = nullptr; g.bar_Cs = nullptr;
     return g;
 }
 template <typename R>
@@ -183,18 +185,24 @@ int wfilter_fwd(const kvae_dims* d, const kvae_filter_fwd* io) {
 }
 template <typename R, int N, int P, int K>
 int wfilter_bwd(const kvae_dims* d, const kvae_filter_bwd* io) {
-    using PG = FilterParamGrads<N, P, K>;
     FilterBwdArgs<R> g = mkb<R>(d, io);
+    const long rows = (long)(d->T + 1) * d->B;
+    std::vector<R> bar_As(rows * N * N), bar_Cs(rows * P * N);
+    g.bar_As = bar_As.data();
+    g.bar_Cs = bar_Cs.data();
     auto s = std::make_unique<wave::FilterBwdScratch<R, N, P, K>>();
     auto acc = std::make_unique<wave::FilterGradAcc<R, N, P, K>>();
     acc->zero();
     for (int b = 0; b < d->B; ++b) wave::filter_backward_sequence<R, N, P, K>(g, b, *s, *acc);
-    std::vector<R> row(PG::LEN);
+    std::vector<R> row(N * N + P * P);
     acc->store(row.data());
-    put<R>(io->d_A_K, row.data() + PG::OFF_A, K * N * N);
-    put<R>(io->d_C_K, row.data() + PG::OFF_C, K * P * N);
-    put<R>(io->d_Q, row.data() + PG::OFF_Q, N * N);
-    put<R>(io->d_R, row.data() + PG::OFF_R, P * P);
+    put<R>(io->d_Q, row.data(), N * N);
+    put<R>(io->d_R, row.data() + N * N, P * P);
+    std::vector<R> dA(K * N * N), dC(K * P * N);
+    wave::mix_adjoint_host<R, N, P, K>(rows, g.f.alpha, g.bar_As, g.bar_Cs, g.f.A_K, g.f.C_K,
+                                       g.d_alpha, dA.data(), dC.data());
+    put<R>(io->d_A_K, dA.data(), K * N * N);
+    put<R>(io->d_C_K, dC.data(), K * P * N);
     return 0;
 }
 template <typename R, int N, int P, int K>

@@ -120,3 +120,20 @@ def test_wave_large_state_f32(be):
                     burn_in=2)
     KC.check_elbo(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=3)
     KC.check_elbo(be, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)
+
+
+def test_wave_long_sequence_drift_f32(be):
+    """T = 1000 at z_dim 32 in float32 against the float64 oracle: rounding must
+    not accumulate over the sequence (outputs and gradients stay within 1e-4)."""
+    KC.check_filter(be, T=1000, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=31,
+                    mask_kind="binary", burn_in=3)
+    KC.check_smooth(be, T=1000, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=32, sample=True,
+                    burn_in=3)
+    KC.check_elbo(be, T=1000, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=33)
+
+
+def test_lane_long_sequence_drift_f32(be):
+    KC.check_filter(be, T=1000, B=3, n=4, p=2, K=3, dtype=torch.float32, seed=34,
+                    mask_kind="binary", burn_in=3)
+    KC.check_smooth(be, T=1000, B=3, n=4, p=2, K=3, dtype=torch.float32, seed=35, sample=True)
+    KC.check_elbo(be, T=1000, B=3, n=4, p=2, K=3, dtype=torch.float32, seed=36)
