@@ -83,7 +83,9 @@ def kernel_bytes(n, p, K, el):
     m, c, A, Cm = n, n * n, n * n, p * n
     return {
         "filter_forward": el * ((p + K) + (2 * m + 2 * c + A + Cm)),
-        "filter_backward": el * ((p + 2 * K + 2 * m + 2 * c) + (2 * m + 2 * c) + (p + K)),
+        # reads a, alpha, saved m/P/m_pred/P_pred, upstream grads of the four mean/cov
+        # outputs and of mat_As/mat_Cs; writes d_a, d_alpha
+        "filter_backward": el * ((p + K + 2 * m + 2 * c) + (2 * m + 2 * c + A + Cm) + (p + K)),
         "smooth_forward": el * ((2 * m + 2 * c + A + Cm + n + p) + (m + c + n + p)),
         "smooth_backward": el * ((2 * m + 2 * c + A + Cm + n + p + m + c) + (m + c + n + p)
                                  + (2 * m + 2 * c + A + Cm)),
