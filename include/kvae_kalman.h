@@ -192,6 +192,28 @@ int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Recurrent part of the LSTM dynamics-parameter network, one layer over a whole
+ * sequence: kvae/dynamics_parameter_network.py:46-58 (LSTMModel.forward, i.e.
+ * torch.nn.LSTM with gate order i,f,g,o and zero initial state), float32 only,
+ * hidden size H in {32, 64, 128, 256}.  Used when the mixing weights of all
+ * steps can be produced up front (no observation mask).
+ *
+ * forward: gates (T,B,4H) holds on entry the input projection
+ *   X_t W_ih^T + b_ih + b_hh of every step (one time-batched library GEMM done
+ *   by the caller) and on return the activated gates i,f,g,o; WhhT is W_hh
+ *   transposed, (H,4H); h, c: (T,B,H) outputs.
+ * backward: dh (T,B,H) holds on entry the gradient w.r.t. every h_t and is used
+ *   as the accumulator of the recurrent gradient (overwritten); dgates (T,B,4H)
+ *   receives the gradient w.r.t. the gate pre-activations, from which the caller
+ *   forms dW_ih, dW_hh, db and dX with time-batched library GEMMs; Whh is
+ *   (4H,H); dc_work: (B,H) scratch.
+ */
+int kvae_lstm_layer_forward(int T, int B, int H, void *gates, const void *WhhT, void *h, void *c,
+                            void *stream);
+int kvae_lstm_layer_backward(int T, int B, int H, const void *gates, const void *c, void *dh,
+                             const void *Whh, void *dgates, void *dc_work, void *stream);
+
+/* ------------------------------------------------------------------------ */
 enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };
 
 /* Scratch bytes the backward entry points need for their per-wave partial

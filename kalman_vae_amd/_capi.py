@@ -64,6 +64,7 @@ EXPORTS = (
     "kvae_filter_forward", "kvae_filter_backward",
     "kvae_smooth_forward", "kvae_smooth_backward",
     "kvae_elbo_forward", "kvae_elbo_backward",
+    "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
 )
 
 
@@ -134,6 +135,10 @@ def load():
     lib.kvae_supported.restype = C.c_int
     lib.kvae_workspace_bytes.argtypes = [C.POINTER(Dims), C.c_int]
     lib.kvae_workspace_bytes.restype = C.c_size_t
+    lib.kvae_lstm_layer_forward.argtypes = [C.c_int] * 3 + [_vp] * 5
+    lib.kvae_lstm_layer_forward.restype = C.c_int
+    lib.kvae_lstm_layer_backward.argtypes = [C.c_int] * 3 + [_vp] * 7
+    lib.kvae_lstm_layer_backward.restype = C.c_int
     _lib = lib
     return lib
 

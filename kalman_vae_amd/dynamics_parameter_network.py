@@ -8,6 +8,8 @@ reference (kvae/dynamics_parameter_network.py:18-90) so its checkpoints load:
 import torch
 import torch.nn as nn
 
+from . import lstm_function
+
 
 class LSTMModel(nn.Module):
     """nn.LSTM -> Linear -> softmax with the recurrent state cached on the
@@ -22,6 +24,10 @@ class LSTMModel(nn.Module):
         self.linear = nn.Linear(hidden_dim, output_dim)
         self.hidden = None
         self.count = 0
+        # whole-sequence calls on a GPU run the recurrence on the package's HIP
+        # kernels (float32, hidden_dim a multiple of 32); step-by-step calls and
+        # everything else use torch.nn.LSTM
+        self.use_hip_recurrence = True
 
     def clear_hidden_state(self):
         self.hidden = None
@@ -35,6 +41,12 @@ class LSTMModel(nn.Module):
 
     def forward(self, x):
         self.count += 1
+        if (self.use_hip_recurrence and self.hidden is None and x.size(0) > 1
+                and lstm_function.supported(x, self.hidden_dim)):
+            # whole sequence from a fresh state: recurrence on the HIP kernels
+            h, hidden = lstm_function.fused_lstm(x, self.lstm)
+            self.hidden = (hidden[0].detach(), hidden[1].detach())
+            return torch.softmax(self.linear(h), dim=-1)
         if self.hidden is None:
             self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
         h, self.hidden = self.lstm(x, self.hidden)

@@ -1,0 +1,107 @@
+"""Whole-sequence LSTM for the dynamics-parameter network with the recurrence
+on HIP kernels (kalman_vae_amd/csrc/lstm_kernels.hip).
+
+Same function as ``torch.nn.LSTM`` (gate order i,f,g,o, zero initial state) as
+used by the reference's ``LSTMModel.forward`` (kvae/dynamics_parameter_network.py:
+46-58).  Per layer the input projection of all steps and the weight gradients
+are time-batched library GEMMs (torch.addmm / bmm -> rocBLAS); the T dependent
+steps -- recurrent product fused with the cell update, and their adjoints -- are
+the kernels.  MIOpen's LSTM spends ~12 ms per forward+backward at (T=20,
+B=4096, H=128, 2 layers), most of it in one badly shaped weight-gradient GEMM;
+this path needs no per-step library call at all.
+"""
+import torch
+
+from . import _capi as capi
+
+
+def supported(x, hidden_dim):
+    return x.is_cuda and x.dtype == torch.float32 and hidden_dim in (32, 64, 128, 256)
+
+
+def _splitk_tn(a, b, chunk=512):
+    """a^T @ b for tall-skinny a (R,M), b (R,N) with R huge: a split over R keeps
+    every rocBLAS call well shaped (one batched GEMM + a small sum)."""
+    R = a.shape[0]
+    S = R // chunk
+    if S < 4 or R % chunk != 0:
+        return a.t() @ b
+    return torch.bmm(a.view(S, chunk, -1).transpose(1, 2), b.view(S, chunk, -1)).sum(0)
+
+
+class FusedLSTMFunction(torch.autograd.Function):
+    """(x (T,B,in), w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...) ->
+    (top-layer h (T,B,H), h_n (L,B,H), c_n (L,B,H))."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = capi.load()
+        T, B, _ = x.shape
+        L = len(params) // 4
+        H = params[1].shape[1]
+        stream = capi.current_stream_ptr()
+        saved, inp = [], x.contiguous()
+        h_n, c_n = [], []
+        for l in range(L):
+            w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
+            gates = torch.addmm(b_ih + b_hh, inp.reshape(T * B, -1), w_ih.t()).view(T, B, 4 * H)
+            h = torch.empty(T, B, H, dtype=x.dtype, device=x.device)
+            c = torch.empty_like(h)
+            capi.check(lib.kvae_lstm_layer_forward(T, B, H, gates.data_ptr(),
+                                                   w_hh.t().contiguous().data_ptr(),
+                                                   h.data_ptr(), c.data_ptr(), stream))
+            saved += [inp, gates, h, c]
+            h_n.append(h[-1])
+            c_n.append(c[-1])
+            inp = h
+        ctx.save_for_backward(*saved, *params)
+        ctx.L, ctx.H = L, H
+        h_n, c_n = torch.stack(h_n), torch.stack(c_n)
+        ctx.mark_non_differentiable(h_n, c_n)
+        return inp, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, dh_top, _dhn, _dcn):
+        lib = capi.load()
+        L, H = ctx.L, ctx.H
+        tensors = ctx.saved_tensors
+        saved, params = tensors[:4 * L], tensors[4 * L:]
+        T, B, _ = saved[2].shape
+        stream = capi.current_stream_ptr()
+        dh = dh_top.contiguous().clone()
+        dc_work = torch.empty(B, H, dtype=dh.dtype, device=dh.device)
+        grads = [None] * (4 * L)
+        dx = None
+        for l in reversed(range(L)):
+            inp, gates, h, c = saved[4 * l:4 * l + 4]
+            w_ih, w_hh = params[4 * l], params[4 * l + 1]
+            dG = torch.empty_like(gates)
+            capi.check(lib.kvae_lstm_layer_backward(T, B, H, gates.data_ptr(), c.data_ptr(),
+                                                    dh.data_ptr(), w_hh.contiguous().data_ptr(),
+                                                    dG.data_ptr(), dc_work.data_ptr(), stream))
+            dG2 = dG.view(T * B, 4 * H)
+            grads[4 * l] = _splitk_tn(dG2, inp.reshape(T * B, -1))
+            if T > 1:
+                grads[4 * l + 1] = _splitk_tn(dG2[B:], h[:-1].reshape((T - 1) * B, H))
+            else:
+                grads[4 * l + 1] = torch.zeros_like(w_hh)
+            db = dG2.sum(0)
+            grads[4 * l + 2] = db
+            grads[4 * l + 3] = db
+            below = (dG2 @ w_ih).view(T, B, -1)
+            if l > 0:
+                dh = below
+            else:
+                dx = below
+        return (dx, *grads)
+
+
+def fused_lstm(x, lstm):
+    """Run ``lstm`` (a torch.nn.LSTM, unidirectional, sequence-first) on x with
+    zero initial state through the HIP recurrence.  Returns (output, (h_n, c_n))."""
+    params = []
+    for l in range(lstm.num_layers):
+        params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
+                   getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
+    out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
+    return out, (h_n, c_n)

@@ -96,13 +96,16 @@ def test_state_dict_and_weight_network_match_reference(name):
     assert set(sd) == set(ssm.state_dict())
     ssm.load_state_dict(sd)
     tol = 1e-12 if g.dtype == torch.float64 else 1e-5
+    if g.stored_f32:
+        tol = 1e-6   # float64 run stored as float32
     assert rel_err(ssm.mat_Q, g["in.Q"]) < tol
     assert rel_err(ssm.mat_R, g["in.R"]) < tol
     # one call over the whole sequence == the reference's step-by-step calls
     ssm.weight_model.clear_hidden_state()
     w = ssm.weight_model(g["out.filter_as"])
     got = torch.cat([torch.full_like(w[:1], 1.0 / c["K"]), w[:-1]])
-    assert rel_err(got, g["out.weights"]) < (1e-10 if g.dtype == torch.float64 else 1e-5)
+    assert rel_err(got, g["out.weights"]) < (1e-10 if g.dtype == torch.float64
+                                             and not g.stored_f32 else 1e-5)
 
 
 def test_matrix_properties_gates_and_setters():

@@ -1,0 +1,50 @@
+"""HIP LSTM recurrence against torch.nn.LSTM (PyTorch-native kernels): outputs,
+final states and gradients w.r.t. input and all parameters, float32.
+Tolerance 1e-4 relative (max-norm) -- both sides are fp32 with different
+summation orders."""
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("T,B,p,H,L", [(20, 70, 2, 128, 2), (5, 33, 3, 32, 1), (7, 64, 2, 64, 3),
+                                       (1, 40, 2, 128, 2), (3, 1, 16, 128, 2)])
+def test_fused_lstm_matches_torch(T, B, p, H, L):
+    from kalman_vae_amd.lstm_function import fused_lstm
+    torch.manual_seed(T * 100 + B)
+    dev = torch.device("cuda:0")
+    lstm = torch.nn.LSTM(p, H, num_layers=L).to(dev)
+    x = torch.randn(T, B, p, device=dev, requires_grad=True)
+    w = torch.randn(T, B, H, device=dev)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref, (hn, cn) = lstm(x)
+        gref = torch.autograd.grad((ref * w).sum(), [x] + list(lstm.parameters()))
+    out, (hn2, cn2) = fused_lstm(x, lstm)
+    g = torch.autograd.grad((out * w).sum(), [x] + list(lstm.parameters()))
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(hn2, hn) < 1e-5 and rel_err(cn2, cn) < 1e-5
+    names = ["x"] + [n for n, _ in lstm.named_parameters()]
+    bad = [(n, rel_err(a, b)) for n, a, b in zip(names, g, gref) if not rel_err(a, b) < 1e-4]
+    assert not bad, bad
+
+
+def test_weight_model_whole_sequence_equals_stepwise():
+    """LSTMModel: one fused whole-sequence call == the reference's step-by-step
+    calls through torch.nn.LSTM, including the cached final state."""
+    from kalman_vae_amd.dynamics_parameter_network import LSTMModel
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    net = LSTMModel(2, 3, 128, 2).to(dev)
+    x = torch.randn(12, 50, 2, device=dev)
+    net.clear_hidden_state()
+    whole = net(x)
+    h_whole = net.hidden
+    net.clear_hidden_state()
+    with torch.backends.cudnn.flags(enabled=False):
+        steps = torch.cat([net(x[t:t + 1]) for t in range(12)])
+    assert rel_err(whole, steps) < 1e-5
+    assert rel_err(h_whole[0], net.hidden[0]) < 1e-5
+    assert rel_err(h_whole[1], net.hidden[1]) < 1e-5
