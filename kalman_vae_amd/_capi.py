@@ -65,6 +65,7 @@ EXPORTS = (
     "kvae_smooth_forward", "kvae_smooth_backward",
     "kvae_elbo_forward", "kvae_elbo_backward",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
+    "kvae_lstm2_forward", "kvae_lstm2_backward",
 )
 
 
@@ -139,6 +140,10 @@ def load():
     lib.kvae_lstm_layer_forward.restype = C.c_int
     lib.kvae_lstm_layer_backward.argtypes = [C.c_int] * 3 + [_vp] * 7
     lib.kvae_lstm_layer_backward.restype = C.c_int
+    lib.kvae_lstm2_forward.argtypes = [C.c_int] * 3 + [_vp] * 14
+    lib.kvae_lstm2_forward.restype = C.c_int
+    lib.kvae_lstm2_backward.argtypes = [C.c_int] * 2 + [_vp] * 11
+    lib.kvae_lstm2_backward.restype = C.c_int
     _lib = lib
     return lib
 

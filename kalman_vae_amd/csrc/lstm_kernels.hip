@@ -102,6 +102,7 @@ lstm_step_forward_kernel(int B, float* __restrict__ gates,
         // stage h_{t-1}[r0 : r0+32][0 : H] in LDS
         stage_tile<H>(h_prev + (long)r0 * H, H, B - r0, a_tile);
         __syncthreads();
+#pragma unroll 1
         for (int kk0 = 0; kk0 < NKK; kk0 += KCH) {
             if (kk0 + KCH < NKK) {
 #pragma unroll
@@ -200,6 +201,7 @@ gemm_acc_kernel(int M, int N, int Kd, const float* __restrict__ A, const float* 
         __syncthreads();
         stage_tile<KC>(A + (long)r0 * Kd + k0, Kd, M - r0, a_tile);
         __syncthreads();
+#pragma unroll 1
         for (int kk0 = 0; kk0 < KC / 2; kk0 += GCH) {
             const int kkg = k0 / 2 + kk0;  // global k-pair index of this chunk
             if (kkg + GCH < nkk) {
@@ -277,6 +279,318 @@ int kvae_lstm_layer_backward(int T, int B, int H, const void* gates, const void*
                                (const float*)Whh, dhp + (t - 1) * BH);
         }
     }
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// Persistent two-layer variant (hidden size 128, the reference's default
+// weight network): ONE launch runs all T steps of both layers for a tile of 32
+// sequences.  A workgroup has four wavefronts; wavefront w owns hidden units
+// [32w, 32w+32) of both layers.  h_t of each layer lives in LDS (double
+// buffered over t), c_t in registers; the weights (3 x 256 KiB) are streamed
+// from L2 every step with register prefetch.  No per-step launch, no global
+// round trip of h between steps; gates/h/c are written out only because the
+// backward needs them.
+// ===========================================================================
+namespace kvae {
+
+constexpr int PH = 128;         // hidden size of the persistent variant
+constexpr int PLDA = PH + 1;    // LDS row stride of an h tile
+constexpr int PG4 = 4 * PH;
+
+// acc[g] += A_tile (32 x 128, LDS) * Bt[:, g*PH + u0 + j], Bt = (128, 512) row-major
+__device__ __forceinline__ void mfma_k128_4gates(f32x16 (&acc)[4], const float* a_tile,
+                                                 const float* __restrict__ Bt, int u0) {
+    const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const float* wb = Bt + u0 + j + (long)hh * PG4;
+    float bcur[KCH][4], bnxt[KCH][4];
+#pragma unroll
+    for (int u = 0; u < KCH; ++u) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bcur[u][g] = wb[(long)(2 * u) * PG4 + g * PH];
+    }
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < PH / 2; kk0 += KCH) {
+        if (kk0 + KCH < PH / 2) {
+#pragma unroll
+            for (int u = 0; u < KCH; ++u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bnxt[u][g] = wb[(long)(2 * (kk0 + KCH + u)) * PG4 + g * PH];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const float a = a_tile[j * PLDA + 2 * (kk0 + u) + hh];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[u][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[u][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[u][2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[u][3], acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bcur[u][g] = bnxt[u][g];
+        }
+    }
+}
+
+// gate activations + cell update for the 16 rows of this lane; writes gates/h/c of
+// step t to global memory and h into the LDS tile for the consumers of h_t.
+__device__ __forceinline__ void cell_epilogue(const f32x16 (&acc)[4], float (&c)[16], int B, int r0,
+                                              int u, int hh, float* __restrict__ gates_t,
+                                              float* __restrict__ h_t, float* __restrict__ c_t,
+                                              float* h_tile) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = acc_row(r, hh), row = r0 + lr;
+        const float ig = sigmoidf_(acc[0][r]);
+        const float fg = sigmoidf_(acc[1][r]);
+        const float gg = tanhf(acc[2][r]);
+        const float og = sigmoidf_(acc[3][r]);
+        c[r] = fg * c[r] + ig * gg;
+        const float h = og * tanhf(c[r]);
+        h_tile[lr * PLDA + u] = h;
+        if (row < B) {
+            const long o = (long)row * PH + u;
+            h_t[o] = h;
+            c_t[o] = c[r];
+            float* gr = gates_t + (long)row * PG4 + u;
+            gr[0] = ig;
+            gr[PH] = fg;
+            gr[2 * PH] = gg;
+            gr[3 * PH] = og;
+        }
+    }
+}
+
+// grid = ceil(B/32), block = 256.  P = input dimension of layer 0 (small).
+template <int P>
+__global__ void __launch_bounds__(256)
+lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      // (T,B,P)
+                                const float* __restrict__ Wih0,                  // (4H,P)
+                                const float* __restrict__ b0,                    // (4H)
+                                const float* __restrict__ Whh0T,                 // (H,4H)
+                                const float* __restrict__ Wih1T,                 // (H,4H)
+                                const float* __restrict__ Whh1T,                 // (H,4H)
+                                const float* __restrict__ b1,                    // (4H)
+                                float* __restrict__ gates0, float* __restrict__ h0,
+                                float* __restrict__ c0g, float* __restrict__ gates1,
+                                float* __restrict__ h1, float* __restrict__ c1g) {
+    __shared__ float hbuf0[2][32 * PLDA];
+    __shared__ float hbuf1[2][32 * PLDA];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const int r0 = blockIdx.x * 32, u0 = 32 * wave, u = u0 + j;
+    const long BH = (long)B * PH, BG = (long)B * PG4;
+
+    float c0[16], c1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    // this lane's layer-0 input weights and biases (4 gates x P)
+    float wx[4][P], bias0[4], bias1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bias0[g] = b0[g * PH + u];
+        bias1[g] = b1[g * PH + u];
+#pragma unroll
+        for (int q = 0; q < P; ++q) wx[g][q] = Wih0[(long)(g * PH + u) * P + q];
+    }
+    for (int t = 0; t < T; ++t) {
+        f32x16 acc[4];
+        // ---- layer 0: input projection (P is tiny: VALU) + recurrent product
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + acc_row(r, hh);
+            float xv[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) xv[q] = row < B ? x[((long)t * B + row) * P + q] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = bias0[g];
+#pragma unroll
+                for (int q = 0; q < P; ++q) s += xv[q] * wx[g][q];
+                acc[g][r] = s;
+            }
+        }
+        if (t > 0) mfma_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
+        cell_epilogue(acc, c0, B, r0, u, hh, gates0 + t * BG, h0 + t * BH, c0g + t * BH,
+                      hbuf0[t & 1]);
+        __syncthreads();
+        // ---- layer 1: input product with h0_t, recurrent product with h1_{t-1}
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = bias1[g];
+        }
+        mfma_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0);
+        if (t > 0) mfma_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
+        cell_epilogue(acc, c1, B, r0, u, hh, gates1 + t * BG, h1 + t * BH, c1g + t * BH,
+                      hbuf1[t & 1]);
+        // hbuf1[t&1] is first read after the barrier of step t+1; hbuf0[(t+1)&1] was
+        // last read before the barrier above
+    }
+}
+
+// acc (32 x 32 tile, columns u0..u0+31) = A_tile (32 x 512, LDS) * W[:, u0 + j], W = (512, 128)
+__device__ __forceinline__ void mfma_k512(f32x16& acc, const float* g_tile,
+                                          const float* __restrict__ W, int u0) {
+    constexpr int LDG = PG4 + 1;
+    const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const float* wb = W + u0 + j + (long)hh * PH;
+    float bcur[GCH], bnxt[GCH];
+#pragma unroll
+    for (int u = 0; u < GCH; ++u) bcur[u] = wb[(long)(2 * u) * PH];
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < PG4 / 2; kk0 += GCH) {
+        if (kk0 + GCH < PG4 / 2) {
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) bnxt[u] = wb[(long)(2 * (kk0 + GCH + u)) * PH];
+        }
+#pragma unroll
+        for (int u = 0; u < GCH; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g_tile[j * LDG + 2 * (kk0 + u) + hh], bcur[u],
+                                                      acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) bcur[u] = bnxt[u];
+    }
+}
+
+// element-wise LSTM cell adjoint for this lane's 16 rows; dh[r] is the total
+// gradient w.r.t. h_t; writes dG (global, step t) and the LDS A-operand tile.
+__device__ __forceinline__ void cell_backward(const float (&dh)[16], float (&dc)[16], int t, int B,
+                                              int r0, int u, int hh,
+                                              const float* __restrict__ gates,
+                                              const float* __restrict__ cg,
+                                              float* __restrict__ dG, float* g_tile) {
+    constexpr int LDG = PG4 + 1;
+    const long BH = (long)B * PH, BG = (long)B * PG4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = acc_row(r, hh), row = r0 + lr;
+        float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f;
+        if (row < B) {
+            const float* gr = gates + t * BG + (long)row * PG4 + u;
+            const float ig = gr[0], fg = gr[PH], gg = gr[2 * PH], og = gr[3 * PH];
+            const long o = (long)row * PH + u;
+            const float tc = tanhf(cg[t * BH + o]);
+            const float cp = t > 0 ? cg[(t - 1) * BH + o] : 0.f;
+            const float dct = dh[r] * og * (1.f - tc * tc) + dc[r];
+            di = dct * gg * ig * (1.f - ig);
+            df = dct * cp * fg * (1.f - fg);
+            dg = dct * ig * (1.f - gg * gg);
+            dout = dh[r] * tc * og * (1.f - og);
+            dc[r] = dct * fg;
+            float* d = dG + t * BG + (long)row * PG4 + u;
+            d[0] = di;
+            d[PH] = df;
+            d[2 * PH] = dg;
+            d[3 * PH] = dout;
+        }
+        float* tl = g_tile + lr * LDG + u;
+        tl[0] = di;
+        tl[PH] = df;
+        tl[2 * PH] = dg;
+        tl[3 * PH] = dout;
+    }
+}
+
+// grid = ceil(B/32), block = 256.  g_h1: gradient w.r.t. the top layer's outputs.
+// Whh1, Wih1, Whh0: (4H, H) row-major as torch stores them.
+__global__ void __launch_bounds__(256)
+lstm2_persistent_backward_kernel(int T, int B, const float* __restrict__ g_h1,
+                                 const float* __restrict__ gates0, const float* __restrict__ c0g,
+                                 const float* __restrict__ gates1, const float* __restrict__ c1g,
+                                 const float* __restrict__ Whh0, const float* __restrict__ Wih1,
+                                 const float* __restrict__ Whh1, float* __restrict__ dG0,
+                                 float* __restrict__ dG1) {
+    __shared__ float g_tile[32 * (PG4 + 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const int r0 = blockIdx.x * 32, u0 = 32 * wave, u = u0 + j;
+    const long BH = (long)B * PH;
+    float dc0[16], dc1[16], dh0rec[16], dh1rec[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dc0[r] = dc1[r] = dh0rec[r] = dh1rec[r] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        float dh[16];
+        // ---- layer 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + acc_row(r, hh);
+            dh[r] = dh1rec[r] + (row < B ? g_h1[t * BH + (long)row * PH + u] : 0.f);
+        }
+        cell_backward(dh, dc1, t, B, r0, u, hh, gates1, c1g, dG1, g_tile);
+        __syncthreads();
+        f32x16 acc;
+        if (t > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mfma_k512(acc, g_tile, Whh1, u0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh1rec[r] = acc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = dh0rec[r];
+        mfma_k512(acc, g_tile, Wih1, u0);   // gradient w.r.t. h0_t through layer 1's input
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = acc[r];
+        __syncthreads();
+        // ---- layer 0
+        cell_backward(dh, dc0, t, B, r0, u, hh, gates0, c0g, dG0, g_tile);
+        __syncthreads();
+        if (t > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mfma_k512(acc, g_tile, Whh0, u0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh0rec[r] = acc[r];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace kvae
+
+extern "C" {
+
+int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, const void* b0,
+                       const void* Whh0T, const void* Wih1T, const void* Whh1T, const void* b1,
+                       void* gates0, void* h0, void* c0, void* gates1, void* h1, void* c1,
+                       void* stream) {
+    if (T < 1 || B < 1 || !x || !Wih0 || !b0 || !Whh0T || !Wih1T || !Whh1T || !b1 || !gates0 ||
+        !h0 || !c0 || !gates1 || !h1 || !c1)
+        return KVAE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((B + 31) / 32);
+#define KVAE_L2F(P_)                                                                            \
+    hipLaunchKernelGGL(kvae::lstm2_persistent_forward_kernel<P_>, grid, dim3(256), 0, s, T, B,  \
+                       (const float*)x, (const float*)Wih0, (const float*)b0,                   \
+                       (const float*)Whh0T, (const float*)Wih1T, (const float*)Whh1T,           \
+                       (const float*)b1, (float*)gates0, (float*)h0, (float*)c0,                \
+                       (float*)gates1, (float*)h1, (float*)c1)
+    switch (P) {
+        case 1: KVAE_L2F(1); break;
+        case 2: KVAE_L2F(2); break;
+        case 3: KVAE_L2F(3); break;
+        case 4: KVAE_L2F(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_L2F
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+int kvae_lstm2_backward(int T, int B, const void* g_h1, const void* gates0, const void* c0,
+                        const void* gates1, const void* c1, const void* Whh0, const void* Wih1,
+                        const void* Whh1, void* dG0, void* dG1, void* stream) {
+    if (T < 1 || B < 1 || !g_h1 || !gates0 || !c0 || !gates1 || !c1 || !Whh0 || !Wih1 || !Whh1 ||
+        !dG0 || !dG1)
+        return KVAE_E_BADARG;
+    hipLaunchKernelGGL(kvae::lstm2_persistent_backward_kernel, dim3((B + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, T, B, (const float*)g_h1, (const float*)gates0,
+                       (const float*)c0, (const float*)gates1, (const float*)c1,
+                       (const float*)Whh0, (const float*)Wih1, (const float*)Whh1, (float*)dG0,
+                       (float*)dG1);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

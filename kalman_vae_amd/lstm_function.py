@@ -15,6 +15,9 @@ import torch
 from . import _capi as capi
 
 
+PERSISTENT = True  # use the one-launch kernels when the shape allows it
+
+
 def supported(x, hidden_dim):
     return x.is_cuda and x.dtype == torch.float32 and hidden_dim in (32, 64, 128, 256)
 
@@ -96,6 +99,54 @@ class FusedLSTMFunction(torch.autograd.Function):
         return (dx, *grads)
 
 
+class FusedLSTM2Function(torch.autograd.Function):
+    """Two layers, hidden size 128, input dimension <= 4: the persistent kernels
+    (one launch for all T steps of both layers, forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+        lib = capi.load()
+        T, B, P = x.shape
+        H = 128
+        x = x.contiguous()
+        new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
+        gates0, h0, c0 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+        gates1, h1, c1 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+        keep = (w_ih0.contiguous(), b_ih0 + b_hh0, w_hh0.t().contiguous(),
+                w_ih1.t().contiguous(), w_hh1.t().contiguous(), b_ih1 + b_hh1)
+        capi.check(lib.kvae_lstm2_forward(
+            T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), gates0.data_ptr(),
+            h0.data_ptr(), c0.data_ptr(), gates1.data_ptr(), h1.data_ptr(), c1.data_ptr(),
+            capi.current_stream_ptr()))
+        ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
+        h_n, c_n = torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]])
+        ctx.mark_non_differentiable(h_n, c_n)
+        return h1, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, g_h1, _dhn, _dcn):
+        lib = capi.load()
+        x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
+        T, B, P = x.shape
+        H = 128
+        g_h1 = g_h1.contiguous()
+        dG0, dG1 = torch.empty_like(gates0), torch.empty_like(gates1)
+        whh0, wih1, whh1 = w_hh0.contiguous(), w_ih1.contiguous(), w_hh1.contiguous()
+        capi.check(lib.kvae_lstm2_backward(
+            T, B, g_h1.data_ptr(), gates0.data_ptr(), c0.data_ptr(), gates1.data_ptr(),
+            c1.data_ptr(), whh0.data_ptr(), wih1.data_ptr(), whh1.data_ptr(), dG0.data_ptr(),
+            dG1.data_ptr(), capi.current_stream_ptr()))
+        d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
+        zero = lambda w: torch.zeros_like(w)
+        dw_ih0 = _splitk_tn(d0, x.reshape(T * B, P))
+        dw_hh0 = _splitk_tn(d0[B:], h0[:-1].reshape(-1, H)) if T > 1 else zero(w_hh0)
+        dw_ih1 = _splitk_tn(d1, h0.reshape(T * B, H))
+        dw_hh1 = _splitk_tn(d1[B:], h1[:-1].reshape(-1, H)) if T > 1 else zero(w_hh1)
+        db0, db1 = d0.sum(0), d1.sum(0)
+        dx = (d0 @ w_ih0).view(T, B, P)
+        return dx, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1
+
+
 def fused_lstm(x, lstm):
     """Run ``lstm`` (a torch.nn.LSTM, unidirectional, sequence-first) on x with
     zero initial state through the HIP recurrence.  Returns (output, (h_n, c_n))."""
@@ -103,5 +154,8 @@ def fused_lstm(x, lstm):
     for l in range(lstm.num_layers):
         params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
                    getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
-    out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
+    if lstm.num_layers == 2 and lstm.hidden_size == 128 and x.shape[2] <= 4 and PERSISTENT:
+        out, h_n, c_n = FusedLSTM2Function.apply(x, *params)
+    else:
+        out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
     return out, (h_n, c_n)

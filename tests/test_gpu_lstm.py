@@ -10,10 +10,14 @@ from golden_util import rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("persistent", [True, False])
 @pytest.mark.parametrize("T,B,p,H,L", [(20, 70, 2, 128, 2), (5, 33, 3, 32, 1), (7, 64, 2, 64, 3),
-                                       (1, 40, 2, 128, 2), (3, 1, 16, 128, 2)])
-def test_fused_lstm_matches_torch(T, B, p, H, L):
+                                       (1, 40, 2, 128, 2), (3, 1, 16, 128, 2), (9, 32, 4, 128, 2),
+                                       (4, 200, 1, 128, 2)])
+def test_fused_lstm_matches_torch(T, B, p, H, L, persistent, monkeypatch):
+    import kalman_vae_amd.lstm_function as lf
     from kalman_vae_amd.lstm_function import fused_lstm
+    monkeypatch.setattr(lf, "PERSISTENT", persistent)
     torch.manual_seed(T * 100 + B)
     dev = torch.device("cuda:0")
     lstm = torch.nn.LSTM(p, H, num_layers=L).to(dev)
