@@ -20,7 +20,7 @@ HEADER = os.path.join(ROOT, "include", "kvae_kalman.h")
 
 def test_library_exports_every_declared_symbol():
     from kalman_vae_amd import _capi as capi
-    declared = set(re.findall(r"\b(kvae_[a-z_]+)\s*\(", open(HEADER).read()))
+    declared = set(re.findall(r"\b(kvae_[a-z0-9_]+)\s*\(", open(HEADER).read()))
     assert declared == set(capi.EXPORTS)
     lib = C.CDLL(capi.LIB_PATH)
     for name in declared:
