@@ -215,21 +215,27 @@ int kvae_lstm_layer_backward(int T, int B, int H, const void *gates, const void 
 
 /* Persistent form for the reference's default network (2 layers, H = 128,
  * layer-0 input dimension P <= 4): ONE launch runs all T steps of both layers
- * for a tile of 32 sequences, h_t in LDS, c_t in registers, weights streamed
- * from L2.  forward: x (T,B,P), Wih0 (4H,P), b0 = b_ih0 + b_hh0 (4H), Whh0T /
- * Wih1T / Whh1T: the (4H,H) matrices transposed to (H,4H), b1 = b_ih1 + b_hh1;
- * outputs gates0/1 (T,B,4H) activated, h0/1 and c0/1 (T,B,H).
- * backward: g_h1 (T,B,H) gradient w.r.t. the top layer's h; Whh0, Wih1, Whh1 as
- * stored (4H,H); outputs dG0, dG1 (T,B,4H), the gate pre-activation gradients
- * (weight/input gradients are time-batched library GEMMs on them).
+ * for a tile of 16 or 32 sequences (chosen by batch size), h_t in LDS, c_t in
+ * registers, weights streamed from L2.
+ * forward: x (T,B,P), Wih0 (4H,P), b0 = b_ih0 + b_hh0 (4H), Whh0T / Wih1T /
+ *   Whh1T: the (4H,H) matrices transposed to (H,4H), b1 = b_ih1 + b_hh1; outputs
+ *   gates0/1 (T,B,4H) activated, h0/1 and c0/1 (T,B,H).
+ * backward: g_h1 (T,B,H) gradient w.r.t. the top layer's h; Wih0 (4H,P); Whh0,
+ *   Wih1, Whh1 as stored (4H,H).  Outputs: dG0, dG1 (T,B,4H), the gate
+ *   pre-activation gradients (operands of the caller's three time-batched
+ *   recurrent/input weight-gradient GEMMs); dx (T,B,P); and
+ *   partial (kvae_lstm2_backward_blocks(B), 4H*(2+P)): per-workgroup sums whose
+ *   column sum over the first axis is [ db0 (4H) | db1 (4H) | dWih0 (4H,P) ].
  */
 int kvae_lstm2_forward(int T, int B, int P, const void *x, const void *Wih0, const void *b0,
                        const void *Whh0T, const void *Wih1T, const void *Whh1T, const void *b1,
                        void *gates0, void *h0, void *c0, void *gates1, void *h1, void *c1,
                        void *stream);
-int kvae_lstm2_backward(int T, int B, const void *g_h1, const void *gates0, const void *c0,
-                        const void *gates1, const void *c1, const void *Whh0, const void *Wih1,
-                        const void *Whh1, void *dG0, void *dG1, void *stream);
+int kvae_lstm2_backward_blocks(int B);
+int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, const void *gates0,
+                        const void *c0, const void *gates1, const void *c1, const void *Wih0,
+                        const void *Whh0, const void *Wih1, const void *Whh1, void *dG0, void *dG1,
+                        void *dx, void *partial, void *stream);
 
 /* ------------------------------------------------------------------------ */
 enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };

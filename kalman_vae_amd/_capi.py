@@ -65,7 +65,7 @@ EXPORTS = (
     "kvae_smooth_forward", "kvae_smooth_backward",
     "kvae_elbo_forward", "kvae_elbo_backward",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
-    "kvae_lstm2_forward", "kvae_lstm2_backward",
+    "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
 )
 
 
@@ -142,7 +142,9 @@ def load():
     lib.kvae_lstm_layer_backward.restype = C.c_int
     lib.kvae_lstm2_forward.argtypes = [C.c_int] * 3 + [_vp] * 14
     lib.kvae_lstm2_forward.restype = C.c_int
-    lib.kvae_lstm2_backward.argtypes = [C.c_int] * 2 + [_vp] * 11
+    lib.kvae_lstm2_backward.argtypes = [C.c_int] * 3 + [_vp] * 15
+    lib.kvae_lstm2_backward_blocks.argtypes = [C.c_int]
+    lib.kvae_lstm2_backward_blocks.restype = C.c_int
     lib.kvae_lstm2_backward.restype = C.c_int
     _lib = lib
     return lib

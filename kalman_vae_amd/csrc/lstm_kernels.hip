@@ -23,6 +23,7 @@
 // the per-lane reads walk a column); the B operand W_hh^T[k][gate*H + unit] is
 // read straight from L2 (lanes = consecutive units, coalesced).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/kvae_kalman.h"
 
@@ -30,7 +31,15 @@ namespace kvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate activations on the hardware exp2/rcp units (about 1 ulp each).  The tanh
+// form has an absolute error near 1e-7 around 0, which is what fp32 gate sums
+// carry anyway; both saturate cleanly (exp2 -> inf gives rcp -> 0).
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008f * x));
+}
 
 // row of accumulator register r for lane-half hh (C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -134,11 +143,11 @@ lstm_step_forward_kernel(int B, float* __restrict__ gates,
             const long o = (long)row * H + u0 + j;
             const float ig = sigmoidf_(acc[0][r]);
             const float fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf(acc[2][r]);
+            const float gg = tanhf_(acc[2][r]);
             const float og = sigmoidf_(acc[3][r]);
             const float cp = c_prev ? c_prev[o] : 0.f;
             const float c = fg * cp + ig * gg;
-            h_out[o] = og * tanhf(c);
+            h_out[o] = og * tanhf_(c);
             c_out[o] = c;
             float* gr = gates + (long)row * G4 + u0 + j;
             gr[0] = ig;
@@ -162,7 +171,7 @@ lstm_cell_backward_kernel(long total, int H, const float* __restrict__ gates,
     const int u = (int)(idx % H);
     const float* gr = gates + row * 4 * H + u;
     const float ig = gr[0], fg = gr[H], gg = gr[2 * H], og = gr[3 * H];
-    const float tc = tanhf(c_t[idx]);
+    const float tc = tanhf_(c_t[idx]);
     const float dht = dh[idx];
     const float dcn = first_in_time_reversed ? 0.f : dc[idx];
     const float dct = dht * og * (1.f - tc * tc) + dcn;
@@ -348,10 +357,10 @@ __device__ __forceinline__ void cell_epilogue(const f32x16 (&acc)[4], float (&c)
         const int lr = acc_row(r, hh), row = r0 + lr;
         const float ig = sigmoidf_(acc[0][r]);
         const float fg = sigmoidf_(acc[1][r]);
-        const float gg = tanhf(acc[2][r]);
+        const float gg = tanhf_(acc[2][r]);
         const float og = sigmoidf_(acc[3][r]);
         c[r] = fg * c[r] + ig * gg;
-        const float h = og * tanhf(c[r]);
+        const float h = og * tanhf_(c[r]);
         h_tile[lr * PLDA + u] = h;
         if (row < B) {
             const long o = (long)row * PH + u;
@@ -433,121 +442,414 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
     }
 }
 
-// acc (32 x 32 tile, columns u0..u0+31) = A_tile (32 x 512, LDS) * W[:, u0 + j], W = (512, 128)
-__device__ __forceinline__ void mfma_k512(f32x16& acc, const float* g_tile,
-                                          const float* __restrict__ W, int u0) {
-    constexpr int LDG = PG4 + 1;
-    const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-    const float* wb = W + u0 + j + (long)hh * PH;
-    float bcur[GCH], bnxt[GCH];
+// ---------------------------------------------------------------------------
+// 16-row variant of the persistent kernels.  With 32-row tiles a batch of a few
+// thousand sequences gives fewer workgroups than the chip has compute units;
+// 16-row tiles (v_mfma_f32_16x16x4_f32) double the workgroup count at the price
+// of streaming the weights twice as often from L2.  A lane owns rows 4s..4s+3
+// (s = lane>>4) and the two adjacent hidden units u0+2c, u0+2c+1 (c = lane&15),
+// so weight loads, h/c/gate stores and LDS writes are all 8-byte accesses.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PLDA16 = PH + 4;     // LDS row stride of a 16-row h tile
+constexpr int LDG16 = PG4 + 4;     // LDS row stride of a 16-row gate-gradient tile
+constexpr int KC16 = 4;            // k-steps (of 4) per prefetch chunk, forward
+constexpr int GC16 = 16;           // k-steps (of 4) per prefetch chunk, backward
+// (chunks twice as long push the kernels past 256 registers and run 1.6x slower)
+
+// acc[g][hf] += A_tile (16 x 128, LDS) * Bt[:, g*PH + u0 + 2c + hf], Bt = (128, 512).
+// The weight operand is streamed from L2 through two register buffers used in
+// turn (no copies, so each MFMA waits only for its own load): one chunk covers
+// KC16 * 8 MFMAs = 256 * KC16 cycles of L2 latency.
+struct WChunk4 {
+    float2 v[KC16][4];
+    __device__ __forceinline__ void load(const float* __restrict__ wb, int kk0) {
 #pragma unroll
-    for (int u = 0; u < GCH; ++u) bcur[u] = wb[(long)(2 * u) * PH];
-#pragma unroll 1
-    for (int kk0 = 0; kk0 < PG4 / 2; kk0 += GCH) {
-        if (kk0 + GCH < PG4 / 2) {
+        for (int u = 0; u < KC16; ++u) {
 #pragma unroll
-            for (int u = 0; u < GCH; ++u) bnxt[u] = wb[(long)(2 * (kk0 + GCH + u)) * PH];
+            for (int g = 0; g < 4; ++g)
+                v[u][g] = *reinterpret_cast<const float2*>(wb + (long)(4 * (kk0 + u)) * PG4 + g * PH);
         }
+    }
+    __device__ __forceinline__ void apply(f32x4 (&acc)[4][2], const float* a_row, int kk0) const {
 #pragma unroll
-        for (int u = 0; u < GCH; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g_tile[j * LDG + 2 * (kk0 + u) + hh], bcur[u],
-                                                      acc, 0, 0, 0);
+        for (int u = 0; u < KC16; ++u) {
+            const float a = a_row[4 * (kk0 + u)];
 #pragma unroll
-        for (int u = 0; u < GCH; ++u) bcur[u] = bnxt[u];
+            for (int g = 0; g < 4; ++g) {
+                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[u][g].x, acc[g][0], 0, 0, 0);
+                acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[u][g].y, acc[g][1], 0, 0, 0);
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void mfma16_k128_4gates(f32x4 (&acc)[4][2], const float* a_tile,
+                                                   const float* __restrict__ Bt, int u0) {
+    static_assert((PH / 4) % (2 * KC16) == 0, "chunk pairs must tile K");
+    const int lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    const float* wb = Bt + u0 + 2 * c + (long)s * PG4;
+    const float* a_row = a_tile + c * PLDA16 + s;
+    WChunk4 b0, b1;
+    b0.load(wb, 0);
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < PH / 4; kk0 += 2 * KC16) {
+        b1.load(wb, kk0 + KC16);
+        b0.apply(acc, a_row, kk0);
+        if (kk0 + 2 * KC16 < PH / 4) b0.load(wb, kk0 + 2 * KC16);
+        b1.apply(acc, a_row, kk0 + KC16);
     }
 }
 
-// element-wise LSTM cell adjoint for this lane's 16 rows; dh[r] is the total
-// gradient w.r.t. h_t; writes dG (global, step t) and the LDS A-operand tile.
-__device__ __forceinline__ void cell_backward(const float (&dh)[16], float (&dc)[16], int t, int B,
-                                              int r0, int u, int hh,
-                                              const float* __restrict__ gates,
-                                              const float* __restrict__ cg,
-                                              float* __restrict__ dG, float* g_tile) {
-    constexpr int LDG = PG4 + 1;
+__device__ __forceinline__ void cell_epilogue16(const f32x4 (&acc)[4][2], float (&cst)[4][2], int B,
+                                                int r0, int ub, int s,
+                                                float* __restrict__ gates_t, float* __restrict__ h_t,
+                                                float* __restrict__ c_t, float* h_tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lr = 4 * s + i, row = r0 + lr;
+        float2 ig, fg, gg, og, hv, cv;
+        ig.x = sigmoidf_(acc[0][0][i]); ig.y = sigmoidf_(acc[0][1][i]);
+        fg.x = sigmoidf_(acc[1][0][i]); fg.y = sigmoidf_(acc[1][1][i]);
+        gg.x = tanhf_(acc[2][0][i]);     gg.y = tanhf_(acc[2][1][i]);
+        og.x = sigmoidf_(acc[3][0][i]); og.y = sigmoidf_(acc[3][1][i]);
+        cv.x = cst[i][0] = fg.x * cst[i][0] + ig.x * gg.x;
+        cv.y = cst[i][1] = fg.y * cst[i][1] + ig.y * gg.y;
+        hv.x = og.x * tanhf_(cv.x);
+        hv.y = og.y * tanhf_(cv.y);
+        *reinterpret_cast<float2*>(h_tile + lr * PLDA16 + ub) = hv;
+        if (row < B) {
+            const long o = (long)row * PH + ub;
+            *reinterpret_cast<float2*>(h_t + o) = hv;
+            *reinterpret_cast<float2*>(c_t + o) = cv;
+            float* gr = gates_t + (long)row * PG4 + ub;
+            *reinterpret_cast<float2*>(gr) = ig;
+            *reinterpret_cast<float2*>(gr + PH) = fg;
+            *reinterpret_cast<float2*>(gr + 2 * PH) = gg;
+            *reinterpret_cast<float2*>(gr + 3 * PH) = og;
+        }
+    }
+}
+
+// grid = ceil(B/16), block = 256.
+template <int P>
+__global__ void __launch_bounds__(256)
+lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
+                                  const float* __restrict__ Wih0, const float* __restrict__ b0,
+                                  const float* __restrict__ Whh0T, const float* __restrict__ Wih1T,
+                                  const float* __restrict__ Whh1T, const float* __restrict__ b1,
+                                  float* __restrict__ gates0, float* __restrict__ h0,
+                                  float* __restrict__ c0g, float* __restrict__ gates1,
+                                  float* __restrict__ h1, float* __restrict__ c1g) {
+    __shared__ __attribute__((aligned(16))) float hbuf0[2][16 * PLDA16];
+    __shared__ __attribute__((aligned(16))) float hbuf1[2][16 * PLDA16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * c;
+    const long BH = (long)B * PH, BG = (long)B * PG4;
+
+    float c0[4][2], c1[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c0[i][0] = c0[i][1] = c1[i][0] = c1[i][1] = 0.f;
+    float wx[4][2][P], bias0[4][2], bias1[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            bias0[g][hf] = b0[g * PH + ub + hf];
+            bias1[g][hf] = b1[g * PH + ub + hf];
+#pragma unroll
+            for (int q = 0; q < P; ++q) wx[g][hf][q] = Wih0[(long)(g * PH + ub + hf) * P + q];
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            float xv[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) xv[q] = row < B ? x[((long)t * B + row) * P + q] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float v = bias0[g][hf];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) v += xv[q] * wx[g][hf][q];
+                    acc[g][hf][i] = v;
+                }
+            }
+        }
+        if (t > 0) mfma16_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
+        cell_epilogue16(acc, c0, B, r0, ub, s, gates0 + t * BG, h0 + t * BH, c0g + t * BH,
+                        hbuf0[t & 1]);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[g][hf][i] = bias1[g][hf];
+            }
+        }
+        mfma16_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0);
+        if (t > 0) mfma16_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
+        cell_epilogue16(acc, c1, B, r0, ub, s, gates1 + t * BG, h1 + t * BH, c1g + t * BH,
+                        hbuf1[t & 1]);
+        // the barrier of step t+1 orders these h1 writes before their first read,
+        // and the barrier above ordered the last reads of hbuf0[(t+1)&1] before now
+    }
+}
+
+// acc[hf] (16 rows x units u0+2c+hf) += g_tile (16 x 512, LDS) * W[:, unit], W = (512, 128)
+struct WChunk1 {
+    float2 v[GC16];
+    __device__ __forceinline__ void load(const float* __restrict__ wb, int kk0) {
+#pragma unroll
+        for (int u = 0; u < GC16; ++u)
+            v[u] = *reinterpret_cast<const float2*>(wb + (long)(4 * (kk0 + u)) * PH);
+    }
+    __device__ __forceinline__ void apply(f32x4 (&acc)[2], const float* a_row, int kk0) const {
+#pragma unroll
+        for (int u = 0; u < GC16; ++u) {
+            const float a = a_row[4 * (kk0 + u)];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[u].y, acc[1], 0, 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ void mfma16_k512(f32x4 (&acc)[2], const float* g_tile,
+                                            const float* __restrict__ W, int u0) {
+    static_assert((PG4 / 4) % (2 * GC16) == 0, "chunk pairs must tile K");
+    const int lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    const float* wb = W + u0 + 2 * c + (long)s * PH;
+    const float* a_row = g_tile + c * LDG16 + s;
+    WChunk1 b0, b1;
+    b0.load(wb, 0);
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < PG4 / 4; kk0 += 2 * GC16) {
+        b1.load(wb, kk0 + GC16);
+        b0.apply(acc, a_row, kk0);
+        if (kk0 + 2 * GC16 < PG4 / 4) b0.load(wb, kk0 + 2 * GC16);
+        b1.apply(acc, a_row, kk0 + GC16);
+    }
+}
+
+// element-wise LSTM cell adjoint for this lane's 4 rows x 2 units; dh is the
+// total gradient w.r.t. h_t.  Writes dG (global, step t) and the LDS A-operand
+// tile, and returns the gate gradients in dgt[row][gate] (zero for rows >= B).
+__device__ __forceinline__ void cell_backward16(const float (&dh)[4][2], float (&dc)[4][2], int t,
+                                                int B, int r0, int ub, int s,
+                                                const float* __restrict__ gates,
+                                                const float* __restrict__ cg,
+                                                float* __restrict__ dG, float* g_tile,
+                                                float2 (&dgt)[4][4]) {
     const long BH = (long)B * PH, BG = (long)B * PG4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int lr = acc_row(r, hh), row = r0 + lr;
-        float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int lr = 4 * s + i, row = r0 + lr;
+        float2 di = {0.f, 0.f}, df = {0.f, 0.f}, dg = {0.f, 0.f}, dout = {0.f, 0.f};
         if (row < B) {
-            const float* gr = gates + t * BG + (long)row * PG4 + u;
-            const float ig = gr[0], fg = gr[PH], gg = gr[2 * PH], og = gr[3 * PH];
-            const long o = (long)row * PH + u;
-            const float tc = tanhf(cg[t * BH + o]);
-            const float cp = t > 0 ? cg[(t - 1) * BH + o] : 0.f;
-            const float dct = dh[r] * og * (1.f - tc * tc) + dc[r];
-            di = dct * gg * ig * (1.f - ig);
-            df = dct * cp * fg * (1.f - fg);
-            dg = dct * ig * (1.f - gg * gg);
-            dout = dh[r] * tc * og * (1.f - og);
-            dc[r] = dct * fg;
-            float* d = dG + t * BG + (long)row * PG4 + u;
-            d[0] = di;
-            d[PH] = df;
-            d[2 * PH] = dg;
-            d[3 * PH] = dout;
+            const float* gr = gates + t * BG + (long)row * PG4 + ub;
+            const float2 ig = *reinterpret_cast<const float2*>(gr);
+            const float2 fg = *reinterpret_cast<const float2*>(gr + PH);
+            const float2 gg = *reinterpret_cast<const float2*>(gr + 2 * PH);
+            const float2 og = *reinterpret_cast<const float2*>(gr + 3 * PH);
+            const long o = (long)row * PH + ub;
+            const float2 cc = *reinterpret_cast<const float2*>(cg + t * BH + o);
+            float2 cp = {0.f, 0.f};
+            if (t > 0) cp = *reinterpret_cast<const float2*>(cg + (t - 1) * BH + o);
+            {
+                const float tc = tanhf_(cc.x);
+                const float dct = dh[i][0] * og.x * (1.f - tc * tc) + dc[i][0];
+                di.x = dct * gg.x * ig.x * (1.f - ig.x);
+                df.x = dct * cp.x * fg.x * (1.f - fg.x);
+                dg.x = dct * ig.x * (1.f - gg.x * gg.x);
+                dout.x = dh[i][0] * tc * og.x * (1.f - og.x);
+                dc[i][0] = dct * fg.x;
+            }
+            {
+                const float tc = tanhf_(cc.y);
+                const float dct = dh[i][1] * og.y * (1.f - tc * tc) + dc[i][1];
+                di.y = dct * gg.y * ig.y * (1.f - ig.y);
+                df.y = dct * cp.y * fg.y * (1.f - fg.y);
+                dg.y = dct * ig.y * (1.f - gg.y * gg.y);
+                dout.y = dh[i][1] * tc * og.y * (1.f - og.y);
+                dc[i][1] = dct * fg.y;
+            }
+            float* d = dG + t * BG + (long)row * PG4 + ub;
+            *reinterpret_cast<float2*>(d) = di;
+            *reinterpret_cast<float2*>(d + PH) = df;
+            *reinterpret_cast<float2*>(d + 2 * PH) = dg;
+            *reinterpret_cast<float2*>(d + 3 * PH) = dout;
         }
-        float* tl = g_tile + lr * LDG + u;
-        tl[0] = di;
-        tl[PH] = df;
-        tl[2 * PH] = dg;
-        tl[3 * PH] = dout;
+        float* tl = g_tile + lr * LDG16 + ub;
+        *reinterpret_cast<float2*>(tl) = di;
+        *reinterpret_cast<float2*>(tl + PH) = df;
+        *reinterpret_cast<float2*>(tl + 2 * PH) = dg;
+        *reinterpret_cast<float2*>(tl + 3 * PH) = dout;
+        dgt[i][0] = di;
+        dgt[i][1] = df;
+        dgt[i][2] = dg;
+        dgt[i][3] = dout;
     }
 }
 
-// grid = ceil(B/32), block = 256.  g_h1: gradient w.r.t. the top layer's outputs.
-// Whh1, Wih1, Whh0: (4H, H) row-major as torch stores them.
+// grid = ceil(B/16), block = 256.  Besides dG0/dG1 (the operands of the
+// time-batched recurrent weight-gradient GEMMs) the kernel forms everything whose
+// library GEMM would be badly shaped: dx = dG0 * Wih0 (T,B,P), and per-workgroup
+// partial sums over (t, rows) of dG0, dG1 (bias gradients) and dG0^T x (layer-0
+// input weights), written to partial[blockIdx.x][ 4H | 4H | 4H*P ].
+template <int P>
 __global__ void __launch_bounds__(256)
-lstm2_persistent_backward_kernel(int T, int B, const float* __restrict__ g_h1,
-                                 const float* __restrict__ gates0, const float* __restrict__ c0g,
-                                 const float* __restrict__ gates1, const float* __restrict__ c1g,
-                                 const float* __restrict__ Whh0, const float* __restrict__ Wih1,
-                                 const float* __restrict__ Whh1, float* __restrict__ dG0,
-                                 float* __restrict__ dG1) {
-    __shared__ float g_tile[32 * (PG4 + 1)];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-    const int r0 = blockIdx.x * 32, u0 = 32 * wave, u = u0 + j;
+lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
+                                   const float* __restrict__ x,
+                                   const float* __restrict__ gates0, const float* __restrict__ c0g,
+                                   const float* __restrict__ gates1, const float* __restrict__ c1g,
+                                   const float* __restrict__ Wih0,
+                                   const float* __restrict__ Whh0, const float* __restrict__ Wih1,
+                                   const float* __restrict__ Whh1, float* __restrict__ dG0,
+                                   float* __restrict__ dG1, float* __restrict__ dx,
+                                   float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float g_tile[16 * LDG16];
+    __shared__ float dx_part[4][16][P];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * c;
     const long BH = (long)B * PH;
-    float dc0[16], dc1[16], dh0rec[16], dh1rec[16];
+    float dc0[4][2], dc1[4][2];
+    f32x4 dh0rec[2], dh1rec[2];
+    float sb0[4][2], sb1[4][2], sw[4][2][P], wx[4][2][P];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dc0[r] = dc1[r] = dh0rec[r] = dh1rec[r] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        dc0[i][0] = dc0[i][1] = dc1[i][0] = dc1[i][1] = 0.f;
+        dh0rec[0][i] = dh0rec[1][i] = dh1rec[0][i] = dh1rec[1][i] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            sb0[g][hf] = sb1[g][hf] = 0.f;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                sw[g][hf][q] = 0.f;
+                wx[g][hf][q] = Wih0[(long)(g * PH + ub + hf) * P + q];
+            }
+        }
+    }
     for (int t = T - 1; t >= 0; --t) {
-        float dh[16];
-        // ---- layer 1
+        float dh[4][2];
+        float2 dgt[4][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = r0 + acc_row(r, hh);
-            dh[r] = dh1rec[r] + (row < B ? g_h1[t * BH + (long)row * PH + u] : 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            float2 g = {0.f, 0.f};
+            if (row < B) g = *reinterpret_cast<const float2*>(g_h1 + t * BH + (long)row * PH + ub);
+            dh[i][0] = dh1rec[0][i] + g.x;
+            dh[i][1] = dh1rec[1][i] + g.y;
         }
-        cell_backward(dh, dc1, t, B, r0, u, hh, gates1, c1g, dG1, g_tile);
-        __syncthreads();
-        f32x16 acc;
-        if (t > 0) {
+        cell_backward16(dh, dc1, t, B, r0, ub, s, gates1, c1g, dG1, g_tile, dgt);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mfma_k512(acc, g_tile, Whh1, u0);
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dh1rec[r] = acc[r];
+            for (int g = 0; g < 4; ++g) {
+                sb1[g][0] += dgt[i][g].x;
+                sb1[g][1] += dgt[i][g].y;
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = dh0rec[r];
-        mfma_k512(acc, g_tile, Wih1, u0);   // gradient w.r.t. h0_t through layer 1's input
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[r] = acc[r];
-        __syncthreads();
-        // ---- layer 0
-        cell_backward(dh, dc0, t, B, r0, u, hh, gates0, c0g, dG0, g_tile);
         __syncthreads();
         if (t > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mfma_k512(acc, g_tile, Whh0, u0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dh0rec[r] = acc[r];
+            for (int i = 0; i < 4; ++i) dh1rec[0][i] = dh1rec[1][i] = 0.f;
+            mfma16_k512(dh1rec, g_tile, Whh1, u0);
         }
+        mfma16_k512(dh0rec, g_tile, Wih1, u0);   // adds layer 1's input path to layer 0's recurrent one
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dh[i][0] = dh0rec[0][i];
+            dh[i][1] = dh0rec[1][i];
+        }
+        __syncthreads();
+        cell_backward16(dh, dc0, t, B, r0, ub, s, gates0, c0g, dG0, g_tile, dgt);
+        // layer-0 side products of the gate gradients
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            float xv[P], dxp[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                xv[q] = row < B ? x[((long)t * B + row) * P + q] : 0.f;
+                dxp[q] = 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sb0[g][0] += dgt[i][g].x;
+                sb0[g][1] += dgt[i][g].y;
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    sw[g][0][q] += dgt[i][g].x * xv[q];
+                    sw[g][1][q] += dgt[i][g].y * xv[q];
+                    dxp[q] += dgt[i][g].x * wx[g][0][q] + dgt[i][g].y * wx[g][1][q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                float v = dxp[q];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (c == 0) dx_part[wave][4 * s + i][q] = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * P) {
+            const int lr = threadIdx.x / P, q = threadIdx.x % P;
+            if (r0 + lr < B)
+                dx[((long)t * B + r0 + lr) * P + q] = dx_part[0][lr][q] + dx_part[1][lr][q] +
+                                                      dx_part[2][lr][q] + dx_part[3][lr][q];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh0rec[0][i] = dh0rec[1][i] = 0.f;
+        if (t > 0) mfma16_k512(dh0rec, g_tile, Whh0, u0);
         __syncthreads();
     }
+    // sum the per-lane column accumulators over the four row groups (lane bits 4, 5)
+    float* part = partial + (long)blockIdx.x * (PG4 * (2 + P));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int col = g * PH + ub + hf;
+            float a = sb0[g][hf], b = sb1[g][hf];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (s == 0) {
+                part[col] = a;
+                part[PG4 + col] = b;
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                float w = sw[g][hf][q];
+                w += __shfl_xor(w, 16, 64);
+                w += __shfl_xor(w, 32, 64);
+                if (s == 0) part[2 * PG4 + (long)col * P + q] = w;
+            }
+        }
+    }
+}
+
+// Forward: 16-row tiles while 32-row tiles would leave some of the 256 compute
+// units without a workgroup (32-row tiles stream the weights half as often and win
+// once the chip is full).  KVAE_LSTM_TILE_ROWS=16|32 forces one form (tests, timing).
+// The backward kernel exists in the 16-row form only: it is the faster one at every
+// batch size measured.
+inline bool lstm2_use_16_row_tiles(int B) {
+    const char* e = getenv("KVAE_LSTM_TILE_ROWS");
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 16) return true;
+    if (forced == 32) return false;
+    return (B + 31) / 32 < 256;
 }
 
 }  // namespace kvae
@@ -562,13 +864,19 @@ int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, con
         !h0 || !c0 || !gates1 || !h1 || !c1)
         return KVAE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((B + 31) / 32);
+    const bool rows16 = kvae::lstm2_use_16_row_tiles(B);
+    const dim3 grid(rows16 ? (B + 15) / 16 : (B + 31) / 32);
+#define KVAE_L2F_ARGS                                                                           \
+    T, B, (const float*)x, (const float*)Wih0, (const float*)b0, (const float*)Whh0T,           \
+        (const float*)Wih1T, (const float*)Whh1T, (const float*)b1, (float*)gates0, (float*)h0, \
+        (float*)c0, (float*)gates1, (float*)h1, (float*)c1
 #define KVAE_L2F(P_)                                                                            \
-    hipLaunchKernelGGL(kvae::lstm2_persistent_forward_kernel<P_>, grid, dim3(256), 0, s, T, B,  \
-                       (const float*)x, (const float*)Wih0, (const float*)b0,                   \
-                       (const float*)Whh0T, (const float*)Wih1T, (const float*)Whh1T,           \
-                       (const float*)b1, (float*)gates0, (float*)h0, (float*)c0,                \
-                       (float*)gates1, (float*)h1, (float*)c1)
+    if (rows16)                                                                                 \
+        hipLaunchKernelGGL(kvae::lstm2_persistent_forward16_kernel<P_>, grid, dim3(256), 0, s,  \
+                           KVAE_L2F_ARGS);                                                      \
+    else                                                                                        \
+        hipLaunchKernelGGL(kvae::lstm2_persistent_forward_kernel<P_>, grid, dim3(256), 0, s,    \
+                           KVAE_L2F_ARGS)
     switch (P) {
         case 1: KVAE_L2F(1); break;
         case 2: KVAE_L2F(2); break;
@@ -577,20 +885,34 @@ int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, con
         default: return KVAE_E_UNSUPPORTED;
     }
 #undef KVAE_L2F
+#undef KVAE_L2F_ARGS
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 
-int kvae_lstm2_backward(int T, int B, const void* g_h1, const void* gates0, const void* c0,
-                        const void* gates1, const void* c1, const void* Whh0, const void* Wih1,
-                        const void* Whh1, void* dG0, void* dG1, void* stream) {
-    if (T < 1 || B < 1 || !g_h1 || !gates0 || !c0 || !gates1 || !c1 || !Whh0 || !Wih1 || !Whh1 ||
-        !dG0 || !dG1)
+int kvae_lstm2_backward_blocks(int B) { return B < 1 ? 0 : (B + 15) / 16; }
+
+int kvae_lstm2_backward(int T, int B, int P, const void* g_h1, const void* x, const void* gates0,
+                        const void* c0, const void* gates1, const void* c1, const void* Wih0,
+                        const void* Whh0, const void* Wih1, const void* Whh1, void* dG0, void* dG1,
+                        void* dx, void* partial, void* stream) {
+    if (T < 1 || B < 1 || !g_h1 || !x || !gates0 || !c0 || !gates1 || !c1 || !Wih0 || !Whh0 ||
+        !Wih1 || !Whh1 || !dG0 || !dG1 || !dx || !partial)
         return KVAE_E_BADARG;
-    hipLaunchKernelGGL(kvae::lstm2_persistent_backward_kernel, dim3((B + 31) / 32), dim3(256), 0,
-                       (hipStream_t)stream, T, B, (const float*)g_h1, (const float*)gates0,
-                       (const float*)c0, (const float*)gates1, (const float*)c1,
-                       (const float*)Whh0, (const float*)Wih1, (const float*)Whh1, (float*)dG0,
-                       (float*)dG1);
+#define KVAE_L2B(P_)                                                                             \
+    hipLaunchKernelGGL(kvae::lstm2_persistent_backward16_kernel<P_>, dim3((B + 15) / 16),        \
+                       dim3(256), 0, (hipStream_t)stream, T, B, (const float*)g_h1,              \
+                       (const float*)x, (const float*)gates0, (const float*)c0,                  \
+                       (const float*)gates1, (const float*)c1, (const float*)Wih0,               \
+                       (const float*)Whh0, (const float*)Wih1, (const float*)Whh1, (float*)dG0,  \
+                       (float*)dG1, (float*)dx, (float*)partial)
+    switch (P) {
+        case 1: KVAE_L2B(1); break;
+        case 2: KVAE_L2B(2); break;
+        case 3: KVAE_L2B(3); break;
+        case 4: KVAE_L2B(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_L2B
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

@@ -10,14 +10,18 @@ from golden_util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("persistent", [16, 32, 0])
 @pytest.mark.parametrize("T,B,p,H,L", [(20, 70, 2, 128, 2), (5, 33, 3, 32, 1), (7, 64, 2, 64, 3),
                                        (1, 40, 2, 128, 2), (3, 1, 16, 128, 2), (9, 32, 4, 128, 2),
                                        (4, 200, 1, 128, 2)])
 def test_fused_lstm_matches_torch(T, B, p, H, L, persistent, monkeypatch):
     import kalman_vae_amd.lstm_function as lf
     from kalman_vae_amd.lstm_function import fused_lstm
-    monkeypatch.setattr(lf, "PERSISTENT", persistent)
+    # persistent: tile rows of the one-launch two-layer kernels (both forms are
+    # forced in turn; the library picks by batch size otherwise), 0 = per-step kernels
+    monkeypatch.setattr(lf, "PERSISTENT", bool(persistent))
+    if persistent:
+        monkeypatch.setenv("KVAE_LSTM_TILE_ROWS", str(persistent))
     torch.manual_seed(T * 100 + B)
     dev = torch.device("cuda:0")
     lstm = torch.nn.LSTM(p, H, num_layers=L).to(dev)
