@@ -237,6 +237,21 @@ int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, co
                         const void *Whh0, const void *Wih1, const void *Whh1, void *dG0, void *dG1,
                         void *dx, void *partial, void *stream);
 
+/* Softmax head of the dynamics-parameter network, alpha = softmax(h W^T + b):
+ * kvae/dynamics_parameter_network.py:57-58 (LSTMModel) and 84-90 (last layer of
+ * MLPModel).  float32; h (R,H) with R = T*B rows and H in {32,64,128,256};
+ * W (K,H), b (K), K <= 8; alpha (R,K).
+ * backward: g_alpha (R,K) gradient w.r.t. alpha; outputs d_h (R,H) and
+ *   partial (kvae_softmax_head_backward_blocks(R), K*(H+1)) whose column sum
+ *   over the first axis is [ dW (K,H) | db (K) ].
+ */
+int kvae_softmax_head_forward(long R, int H, int K, const void *h, const void *W, const void *b,
+                              void *alpha, void *stream);
+int kvae_softmax_head_backward_blocks(long R);
+int kvae_softmax_head_backward(long R, int H, int K, const void *h, const void *W,
+                               const void *alpha, const void *g_alpha, void *d_h, void *partial,
+                               void *stream);
+
 /* ------------------------------------------------------------------------ */
 enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };
 

@@ -66,6 +66,8 @@ EXPORTS = (
     "kvae_elbo_forward", "kvae_elbo_backward",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
+    "kvae_softmax_head_forward", "kvae_softmax_head_backward",
+    "kvae_softmax_head_backward_blocks",
 )
 
 
@@ -146,6 +148,12 @@ def load():
     lib.kvae_lstm2_backward_blocks.argtypes = [C.c_int]
     lib.kvae_lstm2_backward_blocks.restype = C.c_int
     lib.kvae_lstm2_backward.restype = C.c_int
+    lib.kvae_softmax_head_forward.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 5
+    lib.kvae_softmax_head_forward.restype = C.c_int
+    lib.kvae_softmax_head_backward.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 7
+    lib.kvae_softmax_head_backward.restype = C.c_int
+    lib.kvae_softmax_head_backward_blocks.argtypes = [C.c_long]
+    lib.kvae_softmax_head_backward_blocks.restype = C.c_int
     _lib = lib
     return lib
 

@@ -1,7 +1,8 @@
 """Dynamics-parameter ("weight") networks: (t,B,a_dim) -> softmax (t,B,K).
 
-These stay ordinary PyTorch modules (MIOpen/rocBLAS on the GPU); the HIP
-kernels only consume the mixing weights they emit.  Parameter names match the
+Ordinary PyTorch modules whose hot parts run on the package's HIP kernels when
+the tensors are float32 on a GPU (LSTM recurrence for whole-sequence calls, the
+Linear+softmax head); on the CPU they are plain torch.  Parameter names match the
 reference (kvae/dynamics_parameter_network.py:18-90) so its checkpoints load:
 ``lstm.*`` + ``linear.*`` for the LSTM model, ``layers.<i>.*`` for the MLP.
 """
@@ -46,11 +47,11 @@ class LSTMModel(nn.Module):
             # whole sequence from a fresh state: recurrence on the HIP kernels
             h, hidden = lstm_function.fused_lstm(x, self.lstm)
             self.hidden = (hidden[0].detach(), hidden[1].detach())
-            return torch.softmax(self.linear(h), dim=-1)
+            return lstm_function.softmax_head(h, self.linear)
         if self.hidden is None:
             self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
         h, self.hidden = self.lstm(x, self.hidden)
-        return torch.softmax(self.linear(h), dim=-1)
+        return lstm_function.softmax_head(h, self.linear)
 
     is_recurrent = True
 
@@ -81,10 +82,9 @@ class MLPModel(nn.Module):
     def forward(self, x):
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i != last:
-                x = torch.relu(x)
-        return torch.softmax(x, dim=-1)
+            if i == last:
+                return lstm_function.softmax_head(x, layer)
+            x = torch.relu(layer(x))
 
     is_recurrent = False
 

@@ -159,6 +159,52 @@ class FusedLSTM2Function(torch.autograd.Function):
         return dx, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1
 
 
+class SoftmaxHeadFunction(torch.autograd.Function):
+    """softmax(h @ W^T + b) over the last axis: h (..., H), W (K, H), b (K)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        lib = capi.load()
+        H, K = h.shape[-1], W.shape[0]
+        h2, Wc = h.contiguous().view(-1, H), W.contiguous()
+        alpha = torch.empty(h2.shape[0], K, dtype=h.dtype, device=h.device)
+        capi.check(lib.kvae_softmax_head_forward(h2.shape[0], H, K, h2.data_ptr(), Wc.data_ptr(),
+                                                 b.contiguous().data_ptr(), alpha.data_ptr(),
+                                                 capi.current_stream_ptr()))
+        ctx.save_for_backward(h2, Wc, alpha)
+        ctx.lead = h.shape[:-1]
+        return alpha.view(*h.shape[:-1], K)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = capi.load()
+        h2, Wc, alpha = ctx.saved_tensors
+        R, H = h2.shape
+        K = Wc.shape[0]
+        g2 = g.contiguous().view(R, K)
+        d_h = torch.empty_like(h2)
+        partial = torch.empty(lib.kvae_softmax_head_backward_blocks(R), K * (H + 1),
+                              dtype=h2.dtype, device=h2.device)
+        capi.check(lib.kvae_softmax_head_backward(R, H, K, h2.data_ptr(), Wc.data_ptr(),
+                                                  alpha.data_ptr(), g2.data_ptr(), d_h.data_ptr(),
+                                                  partial.data_ptr(), capi.current_stream_ptr()))
+        sums = partial.sum(0)
+        return d_h.view(*ctx.lead, H), sums[:K * H].view(K, H), sums[K * H:]
+
+
+def head_supported(h, linear):
+    return (h.is_cuda and h.dtype == torch.float32 and linear.in_features in (32, 64, 128, 256)
+            and linear.out_features <= 8 and linear.bias is not None)
+
+
+def softmax_head(h, linear):
+    """softmax(linear(h), dim=-1) for a torch.nn.Linear with few outputs: the HIP
+    head kernels on a GPU in float32, plain torch otherwise."""
+    if head_supported(h, linear):
+        return SoftmaxHeadFunction.apply(h, linear.weight, linear.bias)
+    return torch.softmax(linear(h), dim=-1)
+
+
 def fused_lstm(x, lstm):
     """Run ``lstm`` (a torch.nn.LSTM, unidirectional, sequence-first) on x with
     zero initial state through the HIP recurrence.  Returns (output, (h_n, c_n))."""

@@ -56,3 +56,23 @@ def test_weight_model_whole_sequence_equals_stepwise():
     assert rel_err(whole, steps) < 1e-5
     assert rel_err(h_whole[0], net.hidden[0]) < 1e-5
     assert rel_err(h_whole[1], net.hidden[1]) < 1e-5
+
+
+@pytest.mark.parametrize("R_shape,H,K", [((20, 70), 128, 3), ((7, 33), 32, 2), ((1000,), 64, 8),
+                                         ((3, 5, 11), 256, 1), ((20, 4096), 128, 3), ((17,), 128, 5)])
+def test_softmax_head_matches_torch(R_shape, H, K):
+    """Linear+softmax head kernels: output, d_h, dW, db against torch (fp32 both
+    sides, different summation order: 1e-4 relative in max-norm)."""
+    from kalman_vae_amd.lstm_function import softmax_head
+    torch.manual_seed(H + K)
+    dev = torch.device("cuda:0")
+    lin = torch.nn.Linear(H, K).to(dev)
+    h = torch.randn(*R_shape, H, device=dev, requires_grad=True)
+    w = torch.randn(*R_shape, K, device=dev)
+    ref = torch.softmax(lin(h), dim=-1)
+    gref = torch.autograd.grad((ref * w).sum(), [h, lin.weight, lin.bias])
+    out = softmax_head(h, lin)
+    g = torch.autograd.grad((out * w).sum(), [h, lin.weight, lin.bias])
+    assert rel_err(out, ref) < 1e-5
+    bad = [(n, rel_err(a, b)) for n, a, b in zip(("h", "W", "b"), g, gref) if not rel_err(a, b) < 1e-4]
+    assert not bad, bad
