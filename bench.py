@@ -242,6 +242,8 @@ def main():
                     help="time only the six HIP kernels with synthetic mixing weights "
                          "(softmax of N(0,1)); no PyTorch weight network, no autograd glue")
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--no-hip-graph", action="store_true",
+                    help="run the step eagerly instead of replaying it as one HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -268,13 +270,30 @@ def main():
     bucket = FlatGradBucket(ssm.parameters()) if world > 1 else None
     sc = SampleControl()
 
-    def step():
+    def eager_step():
         ssm.zero_grad(set_to_none=True)
         a.grad = None
         obj, _ = kalman_elbo(ssm, a, sc, burn_in=args.burn_in)
         (-obj).backward()
         if bucket is not None:
             bucket.all_reduce(average=True)
+
+    # The whole step (weight network, filter, smoother, ELBO terms and their
+    # backward: ~90 launches) replayed as one HIP graph; same kernels, same work.
+    graphed, graph_note = None, None
+    if not args.no_hip_graph and not args.kernels_only:
+        from kalman_vae_amd.graphed import GraphedElboStep
+        try:
+            graphed = GraphedElboStep(ssm, a, sc, burn_in=args.burn_in)
+        except RuntimeError as err:
+            graph_note = str(err)
+
+    def graph_step():
+        graphed(None)            # the synthetic batch already is the static input
+        if bucket is not None:
+            bucket.all_reduce(average=True)
+
+    step = graph_step if graphed is not None else eager_step
 
     def fence():
         torch.cuda.synchronize()
@@ -315,8 +334,11 @@ def main():
                                       if args.kernels_only else f"{args.net} weight network, ")
                                    + "filter+RTS smoother+ELBO terms fwd+bwd",
                        "seq_len": T, "batch_per_gpu": B, "global_batch": B * world,
-                       "burn_in": args.burn_in, "parallelism": f"dp{world}"},
+                       "burn_in": args.burn_in, "parallelism": f"dp{world}",
+                       "hip_graph": graphed is not None},
         }
+        if graph_note:
+            result["config"]["hip_graph_note"] = graph_note
         if not args.no_kernel_timing:
             if not args.kernels_only:
                 kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)

@@ -252,6 +252,36 @@ int kvae_softmax_head_backward(long R, int H, int K, const void *h, const void *
                                const void *alpha, const void *g_alpha, void *d_h, void *partial,
                                void *stream);
 
+/* Cholesky factor L (lower, zeros above) of one small SPD matrix A (n,n) and its
+ * adjoint: the factor torch.distributions.MultivariateNormal builds for the
+ * noise covariances in kvae/state_space_model.py:242-247, 261-266, 409-413.
+ * n <= 64 (float) / 32 (double).  No host synchronisation and no allocation
+ * (usable under HIP graph capture): a non-positive pivot sets bit 8 of *status.
+ * backward: gL (n,n) gradient w.r.t. L (lower triangle used); gA symmetric.
+ */
+int kvae_cholesky_forward(int n, int dtype, const void *A, void *L, void *status, void *stream);
+int kvae_cholesky_backward(int n, int dtype, const void *L, const void *gL, void *gA, void *stream);
+
+/* Deterministic tree sums (no atomics, no memset; same bits on every run).
+ * kvae_column_sum: out (cols) = column sums of the row-major (rows, cols) matrix
+ *   `in` - used for the per-workgroup partial results of the backward kernels.
+ * kvae_vector_sum: out (batch) = total of each of `batch` contiguous vectors of
+ *   length n - the (T,B) -> scalar reduction of the ELBO terms, kvae/misc.py:21-41
+ *   (`aggregate` is this sum times a constant).  scratch: at least
+ *   kvae_vector_sum_scratch_elems(batch, n) elements of the same dtype (may be 0).
+ */
+int kvae_column_sum(long rows, int cols, int dtype, const void *in, void *out, void *stream);
+long kvae_vector_sum_scratch_elems(int batch, long n);
+int kvae_vector_sum(int batch, long n, int dtype, const void *in, void *scratch, void *out,
+                    void *stream);
+
+/* Number of memset / kernel nodes in a captured hipGraph_t (child graphs
+ * included), negative on error.  Host-only helpers with no counterpart in the
+ * reference: the graph-replay wrapper refuses graphs with memset nodes, whose
+ * ordering against dependent kernels is unreliable on ROCm 7.0.              */
+int kvae_graph_count_memset_nodes(void *hip_graph);
+int kvae_graph_count_kernel_nodes(void *hip_graph);
+
 /* ------------------------------------------------------------------------ */
 enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };
 

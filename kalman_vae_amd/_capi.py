@@ -68,6 +68,9 @@ EXPORTS = (
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
     "kvae_softmax_head_backward_blocks",
+    "kvae_cholesky_forward", "kvae_cholesky_backward",
+    "kvae_graph_count_memset_nodes", "kvae_graph_count_kernel_nodes",
+    "kvae_column_sum", "kvae_vector_sum", "kvae_vector_sum_scratch_elems",
 )
 
 
@@ -154,8 +157,30 @@ def load():
     lib.kvae_softmax_head_backward.restype = C.c_int
     lib.kvae_softmax_head_backward_blocks.argtypes = [C.c_long]
     lib.kvae_softmax_head_backward_blocks.restype = C.c_int
+    lib.kvae_cholesky_forward.argtypes = [C.c_int, C.c_int] + [_vp] * 4
+    lib.kvae_cholesky_forward.restype = C.c_int
+    lib.kvae_cholesky_backward.argtypes = [C.c_int, C.c_int] + [_vp] * 4
+    lib.kvae_cholesky_backward.restype = C.c_int
+    for name in ("kvae_graph_count_memset_nodes", "kvae_graph_count_kernel_nodes"):
+        getattr(lib, name).argtypes = [_vp]
+        getattr(lib, name).restype = C.c_int
+    lib.kvae_column_sum.argtypes = [C.c_long, C.c_int, C.c_int, _vp, _vp, _vp]
+    lib.kvae_column_sum.restype = C.c_int
+    lib.kvae_vector_sum.argtypes = [C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]
+    lib.kvae_vector_sum.restype = C.c_int
+    lib.kvae_vector_sum_scratch_elems.argtypes = [C.c_int, C.c_long]
+    lib.kvae_vector_sum_scratch_elems.restype = C.c_long
     _lib = lib
     return lib
+
+
+def column_sum(x):
+    """Column sums of a contiguous 2-D GPU tensor (deterministic, no autograd)."""
+    require_gpu(x)
+    out = torch.empty(x.shape[1], dtype=x.dtype, device=x.device)
+    check(load().kvae_column_sum(x.shape[0], x.shape[1], dtype_code(x.dtype), ptr(x),
+                                 out.data_ptr(), current_stream_ptr()))
+    return out
 
 
 def check(code):

@@ -19,7 +19,8 @@
 namespace kvae {
 
 constexpr int HEAD_BLOCK = 256;           // threads; 16 rows per pass
-constexpr int HEAD_MAX_BLOCKS = 1024;
+constexpr int HEAD_FWD_MAX_BLOCKS = 2048;
+constexpr int HEAD_BWD_MAX_BLOCKS = 512;  // = rows of the partial-sum matrix the caller adds up
 
 template <int V>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&v)[V]) {
@@ -162,15 +163,15 @@ softmax_head_backward_kernel(long R, const float* __restrict__ h, const float* _
         partial[(long)blockIdx.x * NP + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-inline int head_blocks(long R) {
+inline int head_blocks(long R, int cap) {
     const long groups = (R + 15) / 16;
-    return (int)(groups < HEAD_MAX_BLOCKS ? groups : HEAD_MAX_BLOCKS);
+    return (int)(groups < cap ? groups : cap);
 }
 
 template <int H>
 int launch_head_forward(long R, int K, const float* h, const float* W, const float* b, float* alpha,
                         hipStream_t s) {
-    const dim3 grid(head_blocks(R)), block(HEAD_BLOCK);
+    const dim3 grid(head_blocks(R, HEAD_FWD_MAX_BLOCKS)), block(HEAD_BLOCK);
     switch (K) {
 #define KVAE_HF(K_)                                                                              \
     case K_:                                                                                     \
@@ -186,7 +187,7 @@ int launch_head_forward(long R, int K, const float* h, const float* W, const flo
 template <int H>
 int launch_head_backward(long R, int K, const float* h, const float* W, const float* alpha,
                          const float* g, float* d_h, float* partial, hipStream_t s) {
-    const dim3 grid(head_blocks(R)), block(HEAD_BLOCK);
+    const dim3 grid(head_blocks(R, HEAD_BWD_MAX_BLOCKS)), block(HEAD_BLOCK);
     switch (K) {
 #define KVAE_HB(K_)                                                                              \
     case K_:                                                                                     \
@@ -203,7 +204,9 @@ int launch_head_backward(long R, int K, const float* h, const float* W, const fl
 
 extern "C" {
 
-int kvae_softmax_head_backward_blocks(long R) { return R < 1 ? 0 : kvae::head_blocks(R); }
+int kvae_softmax_head_backward_blocks(long R) {
+    return R < 1 ? 0 : kvae::head_blocks(R, kvae::HEAD_BWD_MAX_BLOCKS);
+}
 
 int kvae_softmax_head_forward(long R, int H, int K, const void* h, const void* W, const void* b,
                               void* alpha, void* stream) {

@@ -44,8 +44,6 @@ __device__ __forceinline__ float tanhf_(float x) {
 // row of accumulator register r for lane-half hh (C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-constexpr int LSTM_MAX_H = 256;
-
 // Copy a 32 x COLS tile (rows `src_ld` apart in global memory, rows >= rows_valid
 // read as zero) into LDS with row stride COLS + 1.  All of a lane's 16-byte loads
 // are issued before the first LDS write, so the tile costs one memory latency,

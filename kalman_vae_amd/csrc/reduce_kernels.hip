@@ -1,0 +1,134 @@
+// Deterministic sums used around the kernels: column sums of a (rows, cols)
+// matrix of per-workgroup partial results, and the total of a long vector (the
+// (T,B) -> scalar reduction of the ELBO terms, kvae/misc.py:21-41).  Plain
+// two-level tree sums, no atomics and no memset: the same bits on every run, and
+// nothing in them needs a memset node when a step is captured into a HIP graph.
+#include <hip/hip_runtime.h>
+
+#include "../../include/kvae_kalman.h"
+#include "launch_common.h"
+
+namespace kvae {
+
+constexpr int COLSUM_WAVES = 16;
+
+// out[c] = sum_r in[r * cols + c].  Block = 16 wavefronts x 64 columns; wavefront w
+// adds rows w, w+16, ... (four independent accumulators per lane).
+template <typename T>
+__global__ void __launch_bounds__(64 * COLSUM_WAVES)
+column_sum_kernel(long rows, int cols, const T* __restrict__ in, T* __restrict__ out) {
+    __shared__ T sm[COLSUM_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    if (c < cols) {
+        for (long r = wave; r < rows; r += 4 * COLSUM_WAVES) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long rr = r + (long)u * COLSUM_WAVES;
+                if (rr < rows) acc[u] += in[rr * cols + c];
+            }
+        }
+    }
+    sm[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        T s = T(0);
+#pragma unroll
+        for (int w = 0; w < COLSUM_WAVES; ++w) s += sm[w][lane];
+        out[c] = s;
+    }
+}
+
+constexpr int VECSUM_BLOCK = 1024;
+constexpr long VECSUM_CHUNK = 131072;     // elements per workgroup of the first level
+constexpr int VECSUM_MAX_CHUNKS = 1024;
+
+// out[b * gridDim.x + blockIdx.x] = sum of in[b * n + lo .. hi), lo = blockIdx.x * chunk
+template <typename T>
+__global__ void __launch_bounds__(VECSUM_BLOCK)
+chunk_sum_kernel(long n, long chunk, const T* __restrict__ in, T* __restrict__ out) {
+    __shared__ T sm[VECSUM_BLOCK / 64];
+    const long lo = (long)blockIdx.x * chunk;
+    const long hi = lo + chunk < n ? lo + chunk : n;
+    const T* v = in + (long)blockIdx.y * n;
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    for (long i = lo + threadIdx.x; i < hi; i += 4 * VECSUM_BLOCK) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long ii = i + (long)u * VECSUM_BLOCK;
+            if (ii < hi) acc[u] += v[ii];
+        }
+    }
+    T s = wave_sum<T>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T tot = T(0);
+#pragma unroll
+        for (int w = 0; w < VECSUM_BLOCK / 64; ++w) tot += sm[w];
+        out[(long)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+inline long vecsum_chunks(long n) {
+    long chunks = (n + VECSUM_CHUNK - 1) / VECSUM_CHUNK;
+    return chunks > VECSUM_MAX_CHUNKS ? VECSUM_MAX_CHUNKS : (chunks < 1 ? 1 : chunks);
+}
+
+template <typename T>
+void launch_vector_sum(int batch, long n, const T* in, T* scratch, T* out, hipStream_t s) {
+    const long chunks = vecsum_chunks(n);
+    if (chunks == 1) {
+        hipLaunchKernelGGL((chunk_sum_kernel<T>), dim3(1, batch), dim3(VECSUM_BLOCK), 0, s, n, n, in,
+                           out);
+        return;
+    }
+    const long chunk = (n + chunks - 1) / chunks;
+    hipLaunchKernelGGL((chunk_sum_kernel<T>), dim3((unsigned)chunks, batch), dim3(VECSUM_BLOCK), 0, s,
+                       n, chunk, in, scratch);
+    hipLaunchKernelGGL((chunk_sum_kernel<T>), dim3(1, batch), dim3(VECSUM_BLOCK), 0, s, chunks,
+                       chunks, (const T*)scratch, out);
+}
+
+}  // namespace kvae
+
+extern "C" {
+
+int kvae_column_sum(long rows, int cols, int dtype, const void* in, void* out, void* stream) {
+    if (rows < 0 || cols < 1 || !in || !out) return KVAE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((cols + 63) / 64), block(64 * kvae::COLSUM_WAVES);
+    if (dtype == KVAE_F32)
+        hipLaunchKernelGGL((kvae::column_sum_kernel<float>), grid, block, 0, s, rows, cols,
+                           (const float*)in, (float*)out);
+    else if (dtype == KVAE_F64)
+        hipLaunchKernelGGL((kvae::column_sum_kernel<double>), grid, block, 0, s, rows, cols,
+                           (const double*)in, (double*)out);
+    else
+        return KVAE_E_BADARG;
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+long kvae_vector_sum_scratch_elems(int batch, long n) {
+    if (batch < 1 || n < 1) return 0;
+    const long chunks = kvae::vecsum_chunks(n);
+    return chunks == 1 ? 0 : chunks * batch;
+}
+
+int kvae_vector_sum(int batch, long n, int dtype, const void* in, void* scratch, void* out,
+                    void* stream) {
+    if (batch < 1 || batch > 65535 || n < 1 || !in || !out) return KVAE_E_BADARG;
+    if (kvae::vecsum_chunks(n) > 1 && !scratch) return KVAE_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KVAE_F32)
+        kvae::launch_vector_sum<float>(batch, n, (const float*)in, (float*)scratch, (float*)out, s);
+    else if (dtype == KVAE_F64)
+        kvae::launch_vector_sum<double>(batch, n, (const double*)in, (double*)scratch, (double*)out,
+                                        s);
+    else
+        return KVAE_E_BADARG;
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+}  // extern "C"

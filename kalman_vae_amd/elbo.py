@@ -11,7 +11,7 @@ import torch
 from torch.distributions.utils import _standard_normal
 
 from . import functions as F
-from .misc import _validate_shape, aggregate
+from .misc import _validate_shape, aggregate_weights
 from .sample_control import SampleControl
 
 
@@ -51,9 +51,10 @@ def kalman_elbo(
         ssm.initial_state_mean, ssm.initial_state_covariance, eps)
     if ssm.check_numerics:
         F.raise_on_status(as_.device)
-    agg = lambda v: aggregate(v, sequence_length=T, batch_size=B,
-                              sequence_operation=sequence_operation,
-                              batch_operation=batch_operation)
+    # aggregate(v) (kvae/misc.py:21-41) is a constant times the total of v; the total
+    # is a deterministic tree sum on the HIP library
+    scale = aggregate_weights(T, B, sequence_operation, batch_operation)
+    agg = lambda v: scale * F.total_sum(v)
     w_obs = kalman_weight * agg(obs)
     w_trans = kalman_weight * agg(trans)
     w_post = -kalman_weight * agg(post)

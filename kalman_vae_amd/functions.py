@@ -69,6 +69,67 @@ def _any_K(n, p):
     raise NotImplementedError(f"no HIP kernel compiled for z_dim={n}, a_dim={p}")
 
 
+class SmallCholeskyFunction(torch.autograd.Function):
+    """Lower Cholesky factor of one small SPD matrix (the factor
+    MultivariateNormal builds for Q and R, kvae/state_space_model.py:242-247,
+    261-266, 409-413).  No host sync: failure sets bit 8 of the status word."""
+
+    @staticmethod
+    def forward(ctx, A):
+        capi.require_gpu(A)
+        A = A.contiguous()
+        L = torch.empty_like(A)
+        capi.check(capi.load().kvae_cholesky_forward(
+            A.shape[-1], capi.dtype_code(A.dtype), A.data_ptr(), L.data_ptr(),
+            status_word(A.device).data_ptr(), capi.current_stream_ptr()))
+        ctx.save_for_backward(L)
+        return L
+
+    @staticmethod
+    def backward(ctx, gL):
+        (L,) = ctx.saved_tensors
+        gL = gL.contiguous()
+        gA = torch.empty_like(L)
+        capi.check(capi.load().kvae_cholesky_backward(
+            L.shape[-1], capi.dtype_code(L.dtype), L.data_ptr(), gL.data_ptr(), gA.data_ptr(),
+            capi.current_stream_ptr()))
+        return gA
+
+
+def cholesky_factor(A):
+    if A.dim() != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("cholesky_factor expects one square matrix")
+    return SmallCholeskyFunction.apply(A)
+
+
+class TotalSumFunction(torch.autograd.Function):
+    """Sum of all elements of a GPU tensor as a 0-d tensor (deterministic tree
+    sum on the HIP library; the gradient is the upstream scalar broadcast)."""
+
+    @staticmethod
+    def forward(ctx, v):
+        capi.require_gpu(v)
+        lib = capi.load()
+        vc = v.contiguous()
+        n = vc.numel()
+        out = torch.empty(1, dtype=v.dtype, device=v.device)
+        scratch = torch.empty(max(1, lib.kvae_vector_sum_scratch_elems(1, n)), dtype=v.dtype,
+                              device=v.device)
+        capi.check(lib.kvae_vector_sum(1, n, capi.dtype_code(v.dtype), vc.data_ptr(),
+                                       scratch.data_ptr(), out.data_ptr(),
+                                       capi.current_stream_ptr()))
+        ctx.shape = v.shape
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape)
+
+
+def total_sum(v):
+    return TotalSumFunction.apply(v)
+
+
 class KalmanFilterFunction(torch.autograd.Function):
     """(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in) ->
     (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs).

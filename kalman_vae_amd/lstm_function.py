@@ -33,8 +33,9 @@ def _splitk_tn(a, b):
     S = R // chunk
     if S < 4:
         return a.t() @ b
-    main = torch.bmm(a[:S * chunk].view(S, chunk, -1).transpose(1, 2),
-                     b[:S * chunk].view(S, chunk, -1)).sum(0)
+    slabs = torch.bmm(a[:S * chunk].view(S, chunk, -1).transpose(1, 2),
+                      b[:S * chunk].view(S, chunk, -1))
+    main = capi.column_sum(slabs.view(S, -1)).view(slabs.shape[1:])
     if S * chunk < R:
         main = main + a[S * chunk:].t() @ b[S * chunk:]
     return main
@@ -148,7 +149,7 @@ class FusedLSTM2Function(torch.autograd.Function):
             gates1.data_ptr(), c1.data_ptr(), wih0.data_ptr(), whh0.data_ptr(), wih1.data_ptr(),
             whh1.data_ptr(), dG0.data_ptr(), dG1.data_ptr(), dx.data_ptr(), partial.data_ptr(),
             capi.current_stream_ptr()))
-        sums = partial.sum(0)
+        sums = capi.column_sum(partial)
         db0, db1 = sums[:4 * H], sums[4 * H:8 * H]
         dw_ih0 = sums[8 * H:].view(4 * H, P)
         d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
@@ -188,7 +189,7 @@ class SoftmaxHeadFunction(torch.autograd.Function):
         capi.check(lib.kvae_softmax_head_backward(R, H, K, h2.data_ptr(), Wc.data_ptr(),
                                                   alpha.data_ptr(), g2.data_ptr(), d_h.data_ptr(),
                                                   partial.data_ptr(), capi.current_stream_ptr()))
-        sums = partial.sum(0)
+        sums = capi.column_sum(partial)
         return d_h.view(*ctx.lead, H), sums[:K * H].view(K, H), sums[K * H:]
 
 

@@ -200,8 +200,8 @@ class StateSpaceModel(nn.Module):
                        burn_in):
         T, B = as_.shape[:2]
         A_K, C_K, Q, R = self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R
-        L_Q = torch.linalg.cholesky(Q) if state_noise else None
-        L_R = torch.linalg.cholesky(R) if obs_noise else None
+        L_Q = F.cholesky_factor(Q) if state_noise else None
+        L_R = F.cholesky_factor(R) if obs_noise else None
         mix = lambda w, bases: torch.einsum("bk,kij->bij", w, bases)
         w = torch.full((B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
         m_pred = self.initial_state_mean.expand(B, -1).contiguous()
@@ -270,7 +270,7 @@ class StateSpaceModel(nn.Module):
             if obs_noise:
                 eps_obs = self._draw((T, B, self.a_dim), as_)
         if obs_noise:
-            L_R = torch.linalg.cholesky(self.mat_R)
+            L_R = F.cholesky_factor(self.mat_R)
         out = F.kalman_smooth_steps(
             filter_means, filter_covariances, filter_next_means, filter_next_covariances,
             mat_As, mat_Cs, LR=L_R, eps_state=eps_state, eps_obs=eps_obs,
