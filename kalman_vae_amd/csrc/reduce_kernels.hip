@@ -41,7 +41,7 @@ column_sum_kernel(long rows, int cols, const T* __restrict__ in, T* __restrict__
 }
 
 constexpr int VECSUM_BLOCK = 1024;
-constexpr long VECSUM_CHUNK = 131072;     // elements per workgroup of the first level
+constexpr long VECSUM_CHUNK = 8192;       // elements per workgroup of the first level
 constexpr int VECSUM_MAX_CHUNKS = 1024;
 
 // out[b * gridDim.x + blockIdx.x] = sum of in[b * n + lo .. hi), lo = blockIdx.x * chunk
