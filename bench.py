@@ -353,9 +353,18 @@ def main():
                                  "TFLOPs": kflops[name] * units / sec / 1e12}
             dom = max(kt, key=kt.get)
             achieved = kb[dom] * units / kt[dom] / 1e9
+            # HBM bytes per launch counted by the PMC passes committed under profiles/
+            # (rocprofv3 cannot run inside this process); null for shapes not profiled
+            traffic = None
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                       "pmc_hbm_traffic.json")) as fh:
+                    traffic = json.load(fh).get(f"T{T}_B{B}_n{n}_p{p}_K{K}", {}).get(dom)
+            except OSError:
+                pass
             result["roofline"] = {
                 "kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": kb[dom] * units,
                 "avg_launch_us": kt[dom] * 1e6,
                 "valu_frac": kflops[dom] * units / kt[dom] / 1e12 / VALU_FP32_PEAK_TF,
