@@ -285,8 +285,9 @@ def main():
         from kalman_vae_amd.graphed import GraphedElboStep
         try:
             graphed = GraphedElboStep(ssm, a, sc, burn_in=args.burn_in)
-        except RuntimeError as err:
-            graph_note = str(err)
+        except Exception as err:   # capture refused or failed: time the eager step instead
+            graph_note = f"{type(err).__name__}: {err}"
+            torch.cuda.synchronize()
 
     def graph_step():
         graphed(None)            # the synthetic batch already is the static input

@@ -1,0 +1,434 @@
+// Four lanes per sequence ("quad") form of the small-state filter and smoother.
+//
+// The lane-per-sequence kernels of kalman_core.h issue ~3000 instructions per
+// step from a single wavefront; a batch of a few thousand sequences is only a
+// few dozen wavefronts, so most SIMDs of the chip idle and the kernels are bound
+// by one wavefront's issue rate.  Here the four lanes of a quad share one
+// sequence and a wavefront holds 16 sequences.  Every matrix (n <= 4, p <= 4, so
+// at most 4 x 4) is kept distributed over the quad in BOTH orientations:
+//   c[i] = X[i][q]   (lane q holds column q)     t[j] = X[q][j]   (lane q holds row q)
+// with zeros where q is outside the matrix.  In that layout the float product
+// X^T Y of two column-distributed operands is exactly what the 16-block MFMA
+// v_mfma_f32_4x4x1_16b_f32 computes (block = quad = sequence), 4 instructions per
+// 4x4x4 product, and every product op(A) op(B) of the recursion is such a product
+// of the right orientations; its transpose is the same instruction with the
+// operands swapped.  Orientations that nothing reads are dead code and the
+// compiler drops them.  double has no such MFMA: there the same product runs on
+// DPP quad broadcasts.  Vectors are replicated in the four lanes; the tiny
+// factorisations (inverse of the p x p innovation covariance, Cholesky of an
+// n x n covariance and its adjoint) gather the matrix into every lane and run the
+// lane code of kalman_core.h redundantly.
+//
+// Math, adjoint derivations and the reference line numbers are those of
+// kalman_core.h (filter_forward_sequence etc.); this file only re-expresses them
+// on the distributed layout.  Device code only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "kalman_core.h"
+
+namespace kvae {
+namespace quad {
+
+#define KQ_DEV __device__ __forceinline__
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+KQ_DEV void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+KQ_DEV int qlane() { return threadIdx.x & 3; }
+
+template <int CTRL>
+KQ_DEV float dpp(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+KQ_DEV double dpp(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// value of x in lane K of this quad
+template <int K, typename R>
+KQ_DEV R bc(R x) {
+    return dpp<K * 0x55>(x);
+}
+template <typename R>
+KQ_DEV R xor1(R x) { return dpp<0xB1>(x); }   // quad_perm [1,0,3,2]
+template <typename R>
+KQ_DEV R xor2(R x) { return dpp<0x4E>(x); }   // quad_perm [2,3,0,1]
+
+// sum over the quad, result in all four lanes
+template <typename R>
+KQ_DEV R qsum(R x) {
+    x += xor1(x);
+    x += xor2(x);
+    return x;
+}
+
+// x[q] for this lane's q (0 when q >= N); x is replicated
+template <int N, typename R>
+KQ_DEV R own(const R* x) {
+    const int q = qlane();
+    R r = R(0);
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) r = (q == j) ? x[j] : r;
+    return r;
+}
+
+typedef float f32x4_q __attribute__((ext_vector_type(4)));
+
+// A matrix of M rows and N columns (both <= 4), both orientations.
+template <typename R, int M, int N>
+struct QM {
+    R c[M];   // column q of X, zero when q >= N
+    R t[N];   // row q of X,    zero when q >= M
+};
+
+// C (M entries: column q of the M x N result) {=,+=,-=} X^T Y, X = column q of a
+// Kd x M matrix, Y = column q of a Kd x N matrix.
+template <typename R, int M, int Kd, int N, int MODE>
+KQ_DEV void tn(const R* X, const R* Y, R* C) {
+    if constexpr (std::is_same<R, float>::value) {
+        f32x4_q acc;
+        KV_UNROLL
+        for (int i = 0; i < 4; ++i) acc[i] = (MODE != 0 && i < M) ? C[i] : 0.f;
+        KV_UNROLL
+        for (int k = 0; k < Kd; ++k)
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(MODE == 2 ? -X[k] : X[k], Y[k], acc, 0, 0, 0);
+        KV_UNROLL
+        for (int i = 0; i < M; ++i) C[i] = acc[i];
+    } else {
+        R acc[M];
+        KV_UNROLL
+        for (int i = 0; i < M; ++i) acc[i] = R(0);
+        sfor<0, M>([&](auto i) {
+            KV_UNROLL
+            for (int k = 0; k < Kd; ++k) acc[i.value] += bc<i.value>(X[k]) * Y[k];
+        });
+        KV_UNROLL
+        for (int i = 0; i < M; ++i) {
+            if (MODE == 0) C[i] = acc[i];
+            if (MODE == 1) C[i] += acc[i];
+            if (MODE == 2) C[i] -= acc[i];
+        }
+    }
+}
+
+// Z (M x N) {=,+=,-=} op(A) op(B), flags and MODE as kalman_core.h's gemm:
+// A is stored M x Kd (Kd x M when TA), B is stored Kd x N (N x Kd when TB).
+template <typename R, int M, int Kd, int N, bool TA, bool TB, int MODE, typename MA, typename MB>
+KQ_DEV void mm(const MA& A, const MB& Bm, QM<R, M, N>& Z) {
+    const R* X = TA ? A.c : A.t;     // column q of op(A)^T  (Kd x M)
+    const R* Y = TB ? Bm.t : Bm.c;   // column q of op(B)    (Kd x N)
+    tn<R, M, Kd, N, MODE>(X, Y, Z.c);
+    tn<R, N, Kd, M, MODE>(Y, X, Z.t);
+}
+
+// y (M, replicated) {=,+=,-=} op(A) x ; A stored M x N (N x M when TA)
+template <typename R, int M, int N, bool TA, int MODE, typename MA>
+KQ_DEV void mv(const MA& A, const R* x, R* y) {
+    const R* col = TA ? A.t : A.c;   // column q of op(A)
+    const R xq = own<N>(x);
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) {
+        const R v = qsum(col[i] * xq);
+        if (MODE == 0) y[i] = v;
+        if (MODE == 1) y[i] += v;
+        if (MODE == 2) y[i] -= v;
+    }
+}
+
+// C (M x N) += s * x y^T ; x (M), y (N) replicated
+template <typename R, int M, int N>
+KQ_DEV void qouter_add(R s, const R* x, const R* y, QM<R, M, N>& C) {
+    const R yq = s * own<N>(y), xq = s * own<M>(x);
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) C.c[i] += x[i] * yq;
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) C.t[j] += y[j] * xq;
+}
+
+template <typename R, int N>
+KQ_DEV void qsymmetrize(QM<R, N, N>& X) {
+    KV_UNROLL
+    for (int i = 0; i < N; ++i) {
+        X.c[i] = (X.c[i] + X.t[i]) / R(2);
+        X.t[i] = X.c[i];
+    }
+}
+
+template <typename R, int M, int N>
+KQ_DEV void qzero(QM<R, M, N>& X) {
+    vzero<R, M>(X.c);
+    vzero<R, N>(X.t);
+}
+template <typename R, int M, int N>
+KQ_DEV void qcopy(const QM<R, M, N>& S, QM<R, M, N>& D) {
+    vcopy<R, M>(S.c, D.c);
+    vcopy<R, N>(S.t, D.t);
+}
+template <typename R, int M, int N>
+KQ_DEV void qadd(const QM<R, M, N>& S, QM<R, M, N>& D) {
+    vadd<R, M>(S.c, D.c);
+    vadd<R, N>(S.t, D.t);
+}
+// D = a * S
+template <typename R, int M, int N>
+KQ_DEV void qscale(R a, const QM<R, M, N>& S, QM<R, M, N>& D) {
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) D.c[i] = a * S.c[i];
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) D.t[j] = a * S.t[j];
+}
+// D = a * S + b * U
+template <typename R, int M, int N>
+KQ_DEV void qblend(R a, const QM<R, M, N>& S, R b, const QM<R, M, N>& U, QM<R, M, N>& D) {
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) D.c[i] = a * S.c[i] + b * U.c[i];
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) D.t[j] = a * S.t[j] + b * U.t[j];
+}
+
+// row-major M x N matrix in global memory -> both orientations
+template <typename R, int M, int N>
+KQ_DEV void qload(const R* p, QM<R, M, N>& X) {
+    const int q = qlane();
+    const int qc = q < N ? q : 0, qr = q < M ? q : 0;
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) {
+        const R v = p[i * N + qc];
+        X.c[i] = q < N ? v : R(0);
+    }
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) {
+        const R v = p[qr * N + j];
+        X.t[j] = q < M ? v : R(0);
+    }
+}
+template <typename R, int M, int N>
+KQ_DEV void qload_or_zero(const R* base, long off, QM<R, M, N>& X) {
+    if (base) {
+        qload<R, M, N>(base + off, X);
+    } else {
+        qzero<R, M, N>(X);
+    }
+}
+// lane q stores row q (contiguous)
+template <typename R, int M, int N>
+KQ_DEV void qstore(R* p, const QM<R, M, N>& X, bool active) {
+    const int q = qlane();
+    if (active && q < M) {
+        KV_UNROLL
+        for (int j = 0; j < N; ++j) p[q * N + j] = X.t[j];
+    }
+}
+// replicated vector: every lane loads it (gload); lane 0 of the quad stores it
+template <typename R, int Len>
+KQ_DEV void vstore(R* p, const R* x, bool active) {
+    if (active && qlane() == 0) gstore<R, Len>(p, x);
+}
+
+// full (M x N row-major, replicated in the four lanes) <-> distributed
+template <typename R, int M, int N>
+KQ_DEV void qgather(const QM<R, M, N>& X, R* full) {
+    sfor<0, N>([&](auto j) {
+        KV_UNROLL
+        for (int i = 0; i < M; ++i) full[i * N + j.value] = bc<j.value>(X.c[i]);
+    });
+}
+template <typename R, int M, int N>
+KQ_DEV void qscatter(const R* full, QM<R, M, N>& X) {
+    const int q = qlane();
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) X.c[i] = own<N>(full + i * N);
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) {
+        R r = R(0);
+        KV_UNROLL
+        for (int i = 0; i < M; ++i) r = (q == i) ? full[i * N + j] : r;
+        X.t[j] = r;
+    }
+}
+
+// sum_k w[k] bases[k]
+template <typename R, int K, int M, int N>
+KQ_DEV void qmix(const R* w, const QM<R, M, N>* bases, QM<R, M, N>& out) {
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) {
+        R acc = R(0);
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) acc += w[k] * bases[k].c[i];
+        out.c[i] = acc;
+    }
+    KV_UNROLL
+    for (int j = 0; j < N; ++j) {
+        R acc = R(0);
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) acc += w[k] * bases[k].t[j];
+        out.t[j] = acc;
+    }
+}
+
+// <X, Y> = sum of the element-wise product (replicated result)
+template <typename R, int M, int N>
+KQ_DEV R qdot(const QM<R, M, N>& X, const QM<R, M, N>& Y) {
+    R s = R(0);
+    KV_UNROLL
+    for (int i = 0; i < M; ++i) s += X.c[i] * Y.c[i];
+    return qsum(s);
+}
+
+// S^-1 of an SPD matrix; optionally the replicated Cholesky factor.
+template <typename R, int N>
+KQ_DEV bool qspd_inverse(const QM<R, N, N>& S, QM<R, N, N>& Si, R* L_full = nullptr) {
+    R F[N * N], Fi[N * N], L[N * N];
+    qgather<R, N, N>(S, F);
+    const bool ok = spd_inverse<R, N>(F, Fi, L, nullptr);
+    qscatter<R, N, N>(Fi, Si);
+    if (L_full) vcopy<R, N * N>(L, L_full);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// Filter, forward.  Same statements as filter_forward_sequence.
+// ---------------------------------------------------------------------------
+template <typename R, int N, int P>
+struct QUpdateTerms {
+    QM<R, P, N> M;    // C Pp
+    QM<R, P, P> Si;   // (C Pp C^T + R)^-1
+    QM<R, N, P> F;    // Pp C^T
+    QM<R, N, P> G;    // gain F Si
+    R r[P];           // innovation a - C mp (replicated)
+};
+
+template <typename R, int N, int P>
+KQ_DEV bool qupdate_terms(const QM<R, P, N>& C, const R* mp, const QM<R, N, N>& Pp,
+                          const QM<R, P, P>& Rm, const R* a, QUpdateTerms<R, N, P>& u) {
+    QM<R, P, P> S;
+    mm<R, P, N, N, false, false, 0>(C, Pp, u.M);
+    qcopy<R, P, P>(Rm, S);
+    mm<R, P, N, P, false, true, 1>(u.M, C, S);   // S = M C^T + R
+    const bool ok = qspd_inverse<R, P>(S, u.Si);
+    mm<R, N, N, P, false, true, 0>(Pp, C, u.F);
+    mm<R, N, P, P, false, false, 0>(u.F, u.Si, u.G);
+    vcopy<R, P>(a, u.r);
+    mv<R, P, N, false, 2>(C, mp, u.r);
+    return ok;
+}
+
+template <typename R, int N, int P, int K>
+struct QBases {
+    QM<R, N, N> A[K];
+    QM<R, P, N> C[K];
+};
+template <typename R, int N, int P, int K>
+KQ_DEV void qload_bases(const R* A_K, const R* C_K, QBases<R, N, P, K>& bs) {
+    KV_UNROLL
+    for (int k = 0; k < K; ++k) {
+        qload<R, N, N>(A_K + k * N * N, bs.A[k]);
+        qload<R, P, N>(C_K + k * P * N, bs.C[k]);
+    }
+}
+
+template <typename R, int N, int P, int K>
+KQ_DEV void filter_forward_quad(const FilterFwdArgs<R>& g, int b, bool active) {
+    const long B = g.B;
+    QM<R, P, P> Rm;
+    QM<R, N, N> Q;
+    QBases<R, N, P, K> bs;
+    qload<R, P, P>(g.Rm, Rm);
+    qload<R, N, N>(g.Q, Q);
+    qload_bases<R, N, P, K>(g.A_K, g.C_K, bs);
+    R mp[N];
+    QM<R, N, N> Pp;
+    if (g.carry_per_sequence) {
+        gload<R, N>(g.m_in + (long)b * N, mp);
+        qload<R, N, N>(g.P_in + (long)b * N * N, Pp);
+    } else {
+        gload<R, N>(g.m_in, mp);
+        qload<R, N, N>(g.P_in, Pp);
+    }
+    R w[K], wn[K];
+    gload<R, K>(g.alpha + (long)b * K, w);
+    if (g.As) {
+        QM<R, N, N> A0;
+        qmix<R, K, N, N>(w, bs.A, A0);
+        qstore<R, N, N>(g.As + (long)b * N * N, A0, active);
+    }
+    int st = 0;
+    // the inputs of step t+1 do not depend on the recursion: they are loaded while
+    // step t computes, so their memory latency is off the serial chain
+    R wn_next[K], a_next[P], mu_next = R(1);
+    gload<R, K>(g.alpha + (B + b) * K, wn_next);
+    gload<R, P>(g.a + (long)b * P, a_next);
+    if (g.mask) mu_next = g.mask[b];
+    for (int t = 0; t < g.T; ++t) {
+        const long tb = (long)t * B + b;
+        QM<R, P, N> C;
+        QM<R, N, N> An;
+        R a[P];
+        vcopy<R, K>(wn_next, wn);
+        vcopy<R, P>(a_next, a);
+        const R mu = mu_next;
+        if (t + 1 < g.T) {
+            gload<R, K>(g.alpha + (tb + 2 * B) * K, wn_next);
+            gload<R, P>(g.a + (tb + B) * P, a_next);
+            if (g.mask) mu_next = g.mask[tb + B];
+        }
+        qmix<R, K, P, N>(w, bs.C, C);
+        qmix<R, K, N, N>(wn, bs.A, An);
+        if (g.Cs) qstore<R, P, N>(g.Cs + tb * P * N, C, active);
+        if (g.As) qstore<R, N, N>(g.As + (tb + B) * N * N, An, active);
+
+        QUpdateTerms<R, N, P> u;
+        if (!qupdate_terms<R, N, P>(C, mp, Pp, Rm, a, u)) st |= ST_NONPD_INNOVATION;
+
+        R m[N];
+        QM<R, N, N> Pf;
+        vcopy<R, N>(mp, m);
+        mv<R, N, P, false, 1>(u.G, u.r, m);                    // m_obs = mp + G r
+        qcopy<R, N, N>(Pp, Pf);
+        mm<R, N, P, N, false, false, 2>(u.G, u.M, Pf);         // P_obs = Pp - G (C Pp)
+        if (g.mask) {
+            const R nu = R(1) - mu;
+            KV_UNROLL
+            for (int i = 0; i < N; ++i) m[i] = mu * m[i] + nu * mp[i];
+            qblend<R, N, N>(mu, Pf, nu, Pp, Pf);
+        }
+        if (g.symmetrize) qsymmetrize<R, N>(Pf);
+
+        QM<R, N, N> T1;
+        mv<R, N, N, false, 0>(An, m, mp);                      // m_{t+1|t}
+        mm<R, N, N, N, false, false, 0>(An, Pf, T1);           // An P
+        qcopy<R, N, N>(Q, Pp);
+        mm<R, N, N, N, false, true, 1>(T1, An, Pp);            // An P An^T + Q
+        if (g.symmetrize) qsymmetrize<R, N>(Pp);
+
+        vstore<R, N>(g.m + tb * N, m, active);
+        qstore<R, N, N>(g.Pf + tb * N * N, Pf, active);
+        vstore<R, N>(g.mn + tb * N, mp, active);
+        qstore<R, N, N>(g.Pn + tb * N * N, Pp, active);
+        vcopy<R, K>(wn, w);
+    }
+    if (g.Cs) {
+        QM<R, P, N> C;
+        qmix<R, K, P, N>(w, bs.C, C);
+        qstore<R, P, N>(g.Cs + ((long)g.T * B + b) * P * N, C, active);
+    }
+    if (st && active && g.status && qlane() == 0) atomicOr(g.status, st);
+}
+
+}  // namespace quad
+}  // namespace kvae

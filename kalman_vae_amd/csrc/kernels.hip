@@ -14,7 +14,10 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/kvae_kalman.h"
+#include <cstdlib>
+
 #include "kalman_core.h"
+#include "kalman_quad.h"
 #include "launch_common.h"
 #include "wave_api.h"
 
@@ -39,6 +42,18 @@ template <typename R, int N, int P, int K>
 __global__ void __launch_bounds__(SEQ_BLOCK) filter_forward_kernel(FilterFwdArgs<R> g) {
     const int b = blockIdx.x * SEQ_BLOCK + threadIdx.x;
     if (b < g.B) filter_forward_sequence<R, N, P, K>(g, b);
+}
+
+// Quad form (kalman_quad.h): four lanes per sequence, 16 sequences per wavefront.
+// Lanes of sequences past the end stay in the kernel (the DPP exchanges need all
+// four lanes of a quad), read sequence B-1 and store nothing.
+constexpr int QUAD_SEQS = SEQ_BLOCK / 4;
+
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(SEQ_BLOCK) filter_forward_quad_kernel(FilterFwdArgs<R> g) {
+    const int b = blockIdx.x * QUAD_SEQS + (threadIdx.x >> 2);
+    const bool active = b < g.B;
+    quad::filter_forward_quad<R, N, P, K>(g, active ? b : g.B - 1, active);
 }
 
 template <typename R, int N, int P, int K>
@@ -99,6 +114,19 @@ __global__ void __launch_bounds__(PAIR_BLOCK) elbo_backward_kernel(ElboBwdArgs<R
     X(8, 4, 4)
 
 inline long seq_blocks(long B) { return (B + SEQ_BLOCK - 1) / SEQ_BLOCK; }
+inline long quad_blocks(long B) { return (B + QUAD_SEQS - 1) / QUAD_SEQS; }
+
+// Four lanes per sequence while one lane per sequence would leave SIMDs without a
+// wavefront (1024 SIMDs); KVAE_SEQ_LANES=1|4 forces one form (tests, timing).
+template <int N, int P>
+inline bool use_quad(long B) {
+    if (N > 4 || P > 4) return false;
+    const char* e = getenv("KVAE_SEQ_LANES");
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 1) return false;
+    if (forced == 4) return true;
+    return seq_blocks(B) < 1024;
+}
 inline long seq_rows(long B) { return seq_blocks(B) * (SEQ_BLOCK / WAVE); }
 inline long pair_blocks(long TB) { return (TB + PAIR_BLOCK - 1) / PAIR_BLOCK; }
 inline long pair_rows(long TB) { return pair_blocks(TB) * (PAIR_BLOCK / WAVE); }
@@ -107,6 +135,13 @@ inline long pair_rows(long TB) { return pair_blocks(TB) * (PAIR_BLOCK / WAVE); }
 template <typename R, int N, int P, int K>
 int run_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
     FilterFwdArgs<R> g = make_args<R>(d, io);
+    if constexpr (N <= 4 && P <= 4) {
+        if (use_quad<N, P>(d->B)) {
+            hipLaunchKernelGGL((filter_forward_quad_kernel<R, N, P, K>), dim3(quad_blocks(d->B)),
+                               dim3(SEQ_BLOCK), 0, s, g);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL((filter_forward_kernel<R, N, P, K>), dim3(seq_blocks(d->B)), dim3(SEQ_BLOCK),
                        0, s, g);
     return launch_status();

@@ -47,7 +47,9 @@ class GraphedElboStep:
             ssm.zero_grad(set_to_none=True)
             self.static_as.grad = None
             self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(self.graph, stream=side):
+            # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed)
+            # may keep making runtime calls while this thread captures
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.objective = self._eager()
         finally:
             ssm.check_numerics = self._checked

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP library (through its C ABI) against the
 oracle, on the same seeded problems as the CPU math tests, plus larger batches
 that span many wavefronts and a ragged last wavefront."""
+import os
+
 import pytest
 import torch
 
@@ -12,9 +14,14 @@ pytestmark = pytest.mark.gpu
 DIMS = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)]
 
 
-@pytest.fixture(scope="module")
-def be():
-    return Backend("hip")
+@pytest.fixture(scope="module", params=["lane", "quad"])
+def be(request):
+    """Every test runs against both small-state kernel families: one lane per
+    sequence and four lanes per sequence (the library picks by batch size when
+    the variable is unset; dimensions the quad form does not cover fall back)."""
+    os.environ["KVAE_SEQ_LANES"] = "1" if request.param == "lane" else "4"
+    yield Backend("hip")
+    os.environ.pop("KVAE_SEQ_LANES", None)
 
 
 @pytest.mark.parametrize("n,p,K", DIMS)

@@ -6,7 +6,8 @@ import collections
 import csv
 import sys
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 T, B, n, p, K = map(int, sys.argv[1:6])

@@ -2,7 +2,8 @@
 rocprofv3 to collect per-kernel counters).  usage: run_kernels_once.py B [T n p K iters]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 a = [int(x) for x in sys.argv[1:]]
 B = a[0] if a else 4096
