@@ -191,6 +191,18 @@ typedef struct {
 int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
+ * (and of the imputation path kvae/evaluation.py:100-140): runs
+ * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream`.
+ * The smoother must read what the filter wrote: s->mean_filt == f->mean_filt,
+ * s->cov_filt == f->cov_filt, s->mean_pred == f->mean_pred, s->cov_pred ==
+ * f->cov_pred, s->mat_As == f->mat_As, s->mat_Cs == f->mat_Cs (KVAE_E_BADARG
+ * otherwise).  There is no fused backward entry point: between the two backward
+ * calls the caller's autograd adds the gradients of the other consumers of
+ * mat_As / mat_Cs (the ELBO terms), so they stay two calls.                    */
+int kvae_filter_smooth_forward(const kvae_dims *d, const kvae_filter_fwd *f,
+                               const kvae_smooth_fwd *s, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Recurrent part of the LSTM dynamics-parameter network, one layer over a whole
  * sequence: kvae/dynamics_parameter_network.py:46-58 (LSTMModel.forward, i.e.

@@ -62,7 +62,7 @@ ElboBwd = _ptr_struct("ElboBwd", [
 EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
     "kvae_filter_forward", "kvae_filter_backward",
-    "kvae_smooth_forward", "kvae_smooth_backward",
+    "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
     "kvae_elbo_forward", "kvae_elbo_backward",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
@@ -118,6 +118,10 @@ def declare(lib, prefix="kvae_", with_stream=True):
     for name, argtypes in spec.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if with_stream and hasattr(lib, prefix + "filter_smooth_forward"):
+        fn = getattr(lib, prefix + "filter_smooth_forward")
+        fn.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd), C.POINTER(SmoothFwd), _vp]
         fn.restype = C.c_int
     return lib
 

@@ -430,5 +430,269 @@ KQ_DEV void filter_forward_quad(const FilterFwdArgs<R>& g, int b, bool active) {
     if (st && active && g.status && qlane() == 0) atomicOr(g.status, st);
 }
 
+// ---------------------------------------------------------------------------
+// Filter, backward.  Same statements as filter_backward_sequence; the running
+// parameter-gradient sums hold column q of each gradient matrix.
+// ---------------------------------------------------------------------------
+template <typename R, int N, int P, int K>
+struct QFilterAcc {
+    R A[K][N];   // column q of d A_K[k]
+    R C[K][P];   // column q of d C_K[k]
+    R Q[N];
+    R Rr[P];
+};
+
+// what one backward step reads from global memory
+template <typename R, int N, int P, int K>
+struct QFilterBwdIn {
+    R w[K], wn[K], a[P], mp[N], m[N], mb[N], gmn[N], mu;
+    QM<R, N, N> Pp, Pf, Pb, gPn, Ab;
+    QM<R, P, N> Cb;
+};
+
+template <typename R, int N, int P, int K>
+KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
+                                 QFilterAcc<R, N, P, K>& acc) {
+    const FilterFwdArgs<R>& f = g.f;
+    const long B = f.B;
+    const int T = f.T;
+    const R on = active ? R(1) : R(0);   // sequences past the end add nothing to the sums
+    QM<R, P, P> Rm;
+    QBases<R, N, P, K> bs;
+    qload<R, P, P>(f.Rm, Rm);
+    qload_bases<R, N, P, K>(f.A_K, f.C_K, bs);
+
+    R mpb[N];
+    QM<R, N, N> Ppb;
+    vzero<R, N>(mpb);
+    qzero<R, N, N>(Ppb);
+    R dwn[K];
+    {
+        QM<R, P, N> gC;
+        R wT[K];
+        qload_or_zero<R, P, N>(g.g_Cs, ((long)T * B + b) * P * N, gC);
+        gload<R, K>(f.alpha + ((long)T * B + b) * K, wT);
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) {
+            dwn[k] = qdot<R, P, N>(gC, bs.C[k]);
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) acc.C[k][i] += on * wT[k] * gC.c[i];
+        }
+    }
+
+    // Everything a step reads from memory is independent of the recursion, so the
+    // inputs of step t-1 are loaded while step t computes (two buffers used in turn).
+    auto load_inputs = [&](int t, QFilterBwdIn<R, N, P, K>& in) {
+        const long tb = (long)t * B + b;
+        gload<R, K>(f.alpha + tb * K, in.w);
+        gload<R, K>(f.alpha + (tb + B) * K, in.wn);
+        gload<R, P>(f.a + tb * P, in.a);
+        if (t > 0) {
+            gload<R, N>(f.mn + (tb - B) * N, in.mp);
+            qload<R, N, N>(f.Pn + (tb - B) * N * N, in.Pp);
+        } else if (f.carry_per_sequence) {
+            gload<R, N>(f.m_in + (long)b * N, in.mp);
+            qload<R, N, N>(f.P_in + (long)b * N * N, in.Pp);
+        } else {
+            gload<R, N>(f.m_in, in.mp);
+            qload<R, N, N>(f.P_in, in.Pp);
+        }
+        gload<R, N>(f.m + tb * N, in.m);
+        qload<R, N, N>(f.Pf + tb * N * N, in.Pf);
+        gload_or_zero<R, N>(g.g_m, tb * N, in.mb);
+        qload_or_zero<R, N, N>(g.g_P, tb * N * N, in.Pb);
+        gload_or_zero<R, N>(g.g_mn, tb * N, in.gmn);
+        qload_or_zero<R, N, N>(g.g_Pn, tb * N * N, in.gPn);
+        qload_or_zero<R, N, N>(g.g_As, (tb + B) * N * N, in.Ab);
+        qload_or_zero<R, P, N>(g.g_Cs, tb * P * N, in.Cb);
+        in.mu = f.mask ? f.mask[tb] : R(1);
+    };
+
+    auto step = [&](int t, const QFilterBwdIn<R, N, P, K>& in) {
+        const long tb = (long)t * B + b;
+        R w[K], wn[K], a[P];
+        QM<R, P, N> C;
+        QM<R, N, N> An;
+        vcopy<R, K>(in.w, w);
+        vcopy<R, K>(in.wn, wn);
+        vcopy<R, P>(in.a, a);
+        qmix<R, K, P, N>(w, bs.C, C);
+        qmix<R, K, N, N>(wn, bs.A, An);
+
+        R mp[N], m[N];
+        QM<R, N, N> Pp, Pf;
+        vcopy<R, N>(in.mp, mp);
+        vcopy<R, N>(in.m, m);
+        qcopy<R, N, N>(in.Pp, Pp);
+        qcopy<R, N, N>(in.Pf, Pf);
+
+        // 1. gradients of the step's outputs
+        R mb[N];
+        QM<R, N, N> Pb;
+        vcopy<R, N>(in.mb, mb);
+        qcopy<R, N, N>(in.Pb, Pb);
+        vadd<R, N>(in.gmn, mpb);
+        qadd<R, N, N>(in.gPn, Ppb);
+        if (t < g.burn_in) {
+            vzero<R, N>(mb);
+            qzero<R, N, N>(Pb);
+            vzero<R, N>(mpb);
+            qzero<R, N, N>(Ppb);
+        }
+
+        // 2. time update adjoint
+        QM<R, N, N> Ab;
+        qcopy<R, N, N>(in.Ab, Ab);
+        {
+            if (f.symmetrize) qsymmetrize<R, N>(Ppb);   // H
+            QM<R, N, N> T1, T2;
+            qouter_add<R, N, N>(R(1), mpb, m, Ab);
+            mm<R, N, N, N, false, true, 0>(An, Pf, T1);    // An Pf^T
+            mm<R, N, N, N, false, false, 1>(Ppb, T1, Ab);
+            mm<R, N, N, N, false, false, 0>(An, Pf, T1);   // An Pf
+            mm<R, N, N, N, true, false, 1>(Ppb, T1, Ab);
+            mv<R, N, N, true, 1>(An, mpb, mb);
+            mm<R, N, N, N, true, false, 0>(An, Ppb, T2);   // An^T H
+            mm<R, N, N, N, false, false, 1>(T2, An, Pb);
+            KV_UNROLL
+            for (int i = 0; i < N; ++i) acc.Q[i] += on * Ppb.c[i];
+        }
+
+        // 3. measurement update adjoint
+        QUpdateTerms<R, N, P> u;
+        qupdate_terms<R, N, P>(C, mp, Pp, Rm, a, u);
+        const R mu = in.mu;
+        const R nu = R(1) - mu;
+        if (f.symmetrize) qsymmetrize<R, N>(Pb);   // H
+        QM<R, P, N> Cb;
+        qcopy<R, P, N>(in.Cb, Cb);
+        R mob[N];
+        QM<R, N, N> Pob;
+        KV_UNROLL
+        for (int i = 0; i < N; ++i) {
+            mob[i] = mu * mb[i];
+            mpb[i] = nu * mb[i] + mob[i];
+        }
+        qscale<R, N, N>(mu, Pb, Pob);
+        qblend<R, N, N>(nu, Pb, R(1), Pob, Ppb);
+        QM<R, N, P> Gb;
+        qzero<R, N, P>(Gb);
+        qouter_add<R, N, P>(R(1), mob, u.r, Gb);
+        R rb[P];
+        mv<R, P, N, true, 0>(u.G, mob, rb);               // G^T mob
+        vstore<R, P>(g.d_a + tb * P, rb, active);
+        qouter_add<R, P, N>(R(-1), rb, mp, Cb);
+        mv<R, N, P, true, 2>(C, rb, mpb);                 // mpb -= C^T rb
+        mm<R, N, N, P, false, true, 2>(Pob, u.M, Gb);     // Gb -= Pob M^T
+        QM<R, P, N> Mb;
+        mm<R, P, N, N, true, false, 0>(u.G, Pob, Mb);     // G^T Pob (sign below)
+        mm<R, P, N, N, false, true, 2>(Mb, Pp, Cb);
+        mm<R, N, P, N, true, false, 2>(C, Mb, Ppb);
+        QM<R, N, P> Fb;
+        QM<R, P, P> Sib, Sb, T3;
+        mm<R, N, P, P, false, true, 0>(Gb, u.Si, Fb);     // Gb Si^T
+        mm<R, P, N, P, true, false, 0>(u.F, Gb, Sib);     // F^T Gb
+        mm<R, P, P, P, true, false, 0>(u.Si, Sib, T3);
+        mm<R, P, P, P, false, true, 0>(T3, u.Si, Sb);
+        qscale<R, P, P>(R(-1), Sb, Sb);
+        mm<R, N, P, N, false, false, 1>(Fb, C, Ppb);      // Ppb += Fb C
+        mm<R, P, N, N, true, false, 1>(Fb, Pp, Cb);       // Cb += Fb^T Pp
+        {
+            QM<R, P, N> CPt, T4;
+            mm<R, P, N, N, false, true, 0>(C, Pp, CPt);   // C Pp^T
+            mm<R, P, P, N, false, false, 1>(Sb, CPt, Cb);
+            mm<R, P, P, N, true, false, 1>(Sb, u.M, Cb);
+            mm<R, P, P, N, false, false, 0>(Sb, C, T4);
+            mm<R, N, P, N, true, false, 1>(C, T4, Ppb);   // C^T Sb C
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) acc.Rr[i] += on * Sb.c[i];
+        }
+
+        // 4. mixing adjoint
+        {
+            R da[K];
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) {
+                const R sA = qdot<R, N, N>(Ab, bs.A[k]);
+                const R sC = qdot<R, P, N>(Cb, bs.C[k]);
+                KV_UNROLL
+                for (int i = 0; i < N; ++i) acc.A[k][i] += on * wn[k] * Ab.c[i];
+                KV_UNROLL
+                for (int i = 0; i < P; ++i) acc.C[k][i] += on * w[k] * Cb.c[i];
+                da[k] = dwn[k] + sA;
+                dwn[k] = sC;
+            }
+            vstore<R, K>(g.d_alpha + (tb + B) * K, da, active);
+        }
+    };
+
+    QFilterBwdIn<R, N, P, K> in0, in1;
+    load_inputs(T - 1, in0);
+    for (int t = T - 1; t >= 0; t -= 2) {
+        if (t >= 1) load_inputs(t - 1, in1);
+        step(t, in0);
+        if (t >= 1) {
+            if (t >= 2) load_inputs(t - 2, in0);
+            step(t - 1, in1);
+        }
+    }
+    {
+        QM<R, N, N> gA;
+        R w0[K], da[K];
+        qload_or_zero<R, N, N>(g.g_As, (long)b * N * N, gA);
+        gload<R, K>(f.alpha + (long)b * K, w0);
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) {
+            const R s = qdot<R, N, N>(gA, bs.A[k]);
+            KV_UNROLL
+            for (int i = 0; i < N; ++i) acc.A[k][i] += on * w0[k] * gA.c[i];
+            da[k] = dwn[k] + s;
+        }
+        vstore<R, K>(g.d_alpha + (long)b * K, da, active);
+    }
+    vstore<R, N>(g.d_m_in + (long)b * N, mpb, active);
+    qstore<R, N, N>(g.d_P_in + (long)b * N * N, Ppb, active);
+}
+
+// Sum over the 16 sequences of the wavefront (lanes with equal q), result valid in
+// the first quad.
+template <typename R>
+KQ_DEV R sum_over_quads(R v) {
+    KV_UNROLL
+    for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// row `row` of the partial-sum matrix (layout FilterParamGrads) from the column sums
+template <typename R, int N, int P, int K>
+KQ_DEV void write_filter_partial(const QFilterAcc<R, N, P, K>& acc, R* partial, long row) {
+    using PG = FilterParamGrads<N, P, K>;
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    R* out = partial + row * PG::LEN;
+    KV_UNROLL
+    for (int k = 0; k < K; ++k) {
+        KV_UNROLL
+        for (int i = 0; i < N; ++i) {
+            const R v = sum_over_quads(acc.A[k][i]);
+            if (lane < 4 && q < N) out[PG::OFF_A + k * N * N + i * N + q] = v;
+        }
+        KV_UNROLL
+        for (int i = 0; i < P; ++i) {
+            const R v = sum_over_quads(acc.C[k][i]);
+            if (lane < 4 && q < N) out[PG::OFF_C + k * P * N + i * N + q] = v;
+        }
+    }
+    KV_UNROLL
+    for (int i = 0; i < N; ++i) {
+        const R v = sum_over_quads(acc.Q[i]);
+        if (lane < 4 && q < N) out[PG::OFF_Q + i * N + q] = v;
+    }
+    KV_UNROLL
+    for (int i = 0; i < P; ++i) {
+        const R v = sum_over_quads(acc.Rr[i]);
+        if (lane < 4 && q < P) out[PG::OFF_R + i * P + q] = v;
+    }
+}
+
 }  // namespace quad
 }  // namespace kvae

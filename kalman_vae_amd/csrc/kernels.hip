@@ -57,6 +57,15 @@ __global__ void __launch_bounds__(SEQ_BLOCK) filter_forward_quad_kernel(FilterFw
 }
 
 template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(SEQ_BLOCK) filter_backward_quad_kernel(FilterBwdArgs<R> g) {
+    const int b = blockIdx.x * QUAD_SEQS + (threadIdx.x >> 2);
+    const bool active = b < g.f.B;
+    quad::QFilterAcc<R, N, P, K> acc = {};
+    quad::filter_backward_quad<R, N, P, K>(g, active ? b : g.f.B - 1, active, acc);
+    quad::write_filter_partial<R, N, P, K>(acc, g.partial, blockIdx.x);
+}
+
+template <typename R, int N, int P, int K>
 __global__ void __launch_bounds__(SEQ_BLOCK) filter_backward_kernel(FilterBwdArgs<R> g) {
     constexpr int LEN = FilterParamGrads<N, P, K>::LEN;
     const int b = blockIdx.x * SEQ_BLOCK + threadIdx.x;
@@ -151,9 +160,19 @@ template <typename R, int N, int P, int K>
 int run_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws, size_t ws_bytes,
                         hipStream_t s) {
     using PG = FilterParamGrads<N, P, K>;
+    FilterBwdArgs<R> g = make_args<R>(d, io, ws);
+    if constexpr (N <= 4 && P <= 4) {
+        if (use_quad<N, P>(d->B)) {
+            const long qrows = quad_blocks(d->B);
+            if (ws_bytes < (size_t)qrows * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
+            hipLaunchKernelGGL((filter_backward_quad_kernel<R, N, P, K>), dim3(qrows),
+                               dim3(SEQ_BLOCK), 0, s, g);
+            reduce_filter_grads<R, N, P, K>(io, ws, qrows, s);
+            return launch_status();
+        }
+    }
     const long rows = seq_rows(d->B);
     if (ws_bytes < (size_t)rows * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
-    FilterBwdArgs<R> g = make_args<R>(d, io, ws);
     hipLaunchKernelGGL((filter_backward_kernel<R, N, P, K>), dim3(seq_blocks(d->B)),
                        dim3(SEQ_BLOCK), 0, s, g);
     reduce_filter_grads<R, N, P, K>(io, ws, rows, s);
@@ -254,8 +273,9 @@ size_t kvae_workspace_bytes(const kvae_dims* d, int op) {
     const size_t el = d->dtype == KVAE_F32 ? 4 : 8;
     const long n = d->n, p = d->p, K = d->K;
     switch (op) {
-        case KVAE_OP_FILTER_BWD:
-            return (size_t)seq_rows(d->B) * (K * n * n + K * p * n + n * n + p * p) * el;
+        case KVAE_OP_FILTER_BWD:   // one row per wavefront; the quad form has 16 sequences in one
+            return (size_t)(n <= 4 && p <= 4 ? quad_blocks(d->B) : seq_rows(d->B)) *
+                   (K * n * n + K * p * n + n * n + p * p) * el;
         case KVAE_OP_SMOOTH_BWD:
             return (size_t)seq_rows(d->B) * (p * p) * el;
         case KVAE_OP_ELBO_BWD:
@@ -314,6 +334,17 @@ int kvae_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* wo
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
     return wave_smooth_backward(d, io, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kvae_filter_smooth_forward(const kvae_dims* d, const kvae_filter_fwd* f,
+                               const kvae_smooth_fwd* s, void* stream) {
+    if (!f || !s || !f->mat_As || !f->mat_Cs || s->mean_filt != f->mean_filt ||
+        s->cov_filt != f->cov_filt || s->mean_pred != f->mean_pred ||
+        s->cov_pred != f->cov_pred || s->mat_As != f->mat_As || s->mat_Cs != f->mat_Cs)
+        return KVAE_E_BADARG;
+    const int rc = kvae_filter_forward(d, f, stream);
+    if (rc != KVAE_OK) return rc;
+    return kvae_smooth_forward(d, s, stream);
 }
 
 int kvae_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, void* stream) {

@@ -302,3 +302,32 @@ def kalman_smooth_steps(m, P, mn, Pn, As, Cs, LR=None, eps_state=None, eps_obs=N
 
 def kalman_elbo_terms(a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
     return KalmanElboFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+
+
+@torch.no_grad()
+def kalman_filter_smooth_nograd(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR=None,
+                                eps_state=None, eps_obs=None, symmetrize=True):
+    """Filter then smoother through the single C-ABI call kvae_filter_smooth_forward
+    (inference / imputation: no autograd graph is recorded).  Returns
+    (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs,
+     mean_smooth, cov_smooth, zs, as_resampled)."""
+    capi.require_gpu(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs)
+    a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs = map(
+        _c, (a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs))
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    dims = _dims(T, B, n, p, K, a.dtype, symmetrize, 0)
+    new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+    m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+    As, Cs = new(T + 1, B, n, n), new(T + 1, B, p, n)
+    ms, Ps, zs, ares = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, p)
+    st = status_word(a.device)
+    f = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                  m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2), mean_filt=m,
+                  cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs, status=st)
+    s = capi.fill(capi.SmoothFwd(), mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn,
+                  mat_As=As, mat_Cs=Cs, LR=LR, eps_state=eps_state, eps_obs=eps_obs,
+                  mean_smooth=ms, cov_smooth=Ps, zs=zs, as_resampled=ares, status=st)
+    capi.check(capi.load().kvae_filter_smooth_forward(C.byref(dims), C.byref(f), C.byref(s),
+                                                      capi.current_stream_ptr()))
+    return m, P, mn, Pn, As, Cs, ms, Ps, zs, ares

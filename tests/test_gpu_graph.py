@@ -133,3 +133,29 @@ def test_total_sum_and_gradient(shape, dtype):
     assert abs(float(s) - float(ref)) <= tol * float(v.detach().double().abs().sum())
     (g,) = torch.autograd.grad(3.0 * s, v)
     assert torch.equal(g, torch.full_like(v, 3.0))
+
+
+@pytest.mark.parametrize("n,p,K,dtype", [(4, 2, 3, torch.float32), (16, 8, 4, torch.float64)])
+def test_fused_filter_smooth_call_equals_separate_calls(n, p, K, dtype):
+    """kvae_filter_smooth_forward launches the same kernels as the two separate
+    entry points: results are bitwise equal."""
+    from kalman_vae_amd import functions as F
+    torch.manual_seed(n)
+    dev = torch.device("cuda:0")
+    T, B = 9, 70
+    r = lambda *s: torch.randn(*s, dtype=dtype, device=dev)
+    a, alpha = r(T, B, p), torch.softmax(r(T + 1, B, K), -1)
+    mask = (torch.rand(T, B, device=dev) < 0.7).to(dtype)
+    A_K = torch.eye(n, dtype=dtype, device=dev) * 0.9 + 0.05 * r(K, n, n)
+    C_K = 0.3 * r(K, p, n)
+    Q, R = torch.eye(n, dtype=dtype, device=dev) * 0.5, torch.eye(p, dtype=dtype, device=dev) * 0.3
+    m0, P0 = torch.zeros(n, dtype=dtype, device=dev), torch.eye(n, dtype=dtype, device=dev)
+    LR = torch.linalg.cholesky(R)
+    es, eo = r(T, B, n), r(T, B, p)
+    fused = F.kalman_filter_smooth_nograd(a, alpha, mask, A_K, C_K, Q, R, m0, P0, LR, es, eo)
+    with torch.no_grad():
+        filt = F.kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m0, P0)
+        smo = F.kalman_smooth_steps(*filt, LR=LR, eps_state=es, eps_obs=eo)
+    for x, y in zip(fused, tuple(filt) + tuple(smo)):
+        assert torch.equal(x, y)
+    assert F.read_status(dev) == 0
