@@ -654,6 +654,263 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
     qstore<R, N, N>(g.d_P_in + (long)b * N * N, Ppb, active);
 }
 
+// ---------------------------------------------------------------------------
+// Smoother.  Same statements as smooth_forward_sequence / smooth_backward_sequence.
+// The Cholesky factor of the smoothed covariance (sampling) and its adjoint run
+// replicated in the four lanes on the gathered matrix.
+// ---------------------------------------------------------------------------
+template <typename R, int N, int P>
+KQ_DEV bool qsmooth_emit(const SmoothFwdArgs<R>& g, long tb, const R* mean, const QM<R, N, N>& cov,
+                         const QM<R, P, N>& C, const R* LR, bool active) {
+    bool ok = true;
+    R z[N], ar[P];
+    vcopy<R, N>(mean, z);
+    if (g.eps_s) {
+        R F[N * N], L[N * N], e[N];
+        qgather<R, N, N>(cov, F);
+        ok = cholesky<R, N>(F, L);
+        gload<R, N>(g.eps_s + tb * N, e);
+        gemv<R, N, N, false, 1>(L, e, z);
+    }
+    mv<R, P, N, false, 0>(C, z, ar);
+    if (g.eps_o) {
+        R e[P];
+        gload<R, P>(g.eps_o + tb * P, e);
+        gemv<R, P, P, false, 1>(LR, e, ar);
+    }
+    vstore<R, N>(g.zs + tb * N, z, active);
+    vstore<R, P>(g.ares + tb * P, ar, active);
+    return ok;
+}
+
+template <typename R, int N, int P>
+KQ_DEV void smooth_forward_quad(const SmoothFwdArgs<R>& g, int b, bool active) {
+    const long B = g.B;
+    const int T = g.T;
+    R LR[P * P];
+    if (g.eps_o) {
+        gload<R, P * P>(g.LR, LR);
+    } else {
+        vzero<R, P * P>(LR);
+    }
+    int st = 0;
+    R ms[N];
+    QM<R, N, N> Ps;
+    QM<R, P, N> C;
+    {
+        const long tb = (long)(T - 1) * B + b;
+        gload<R, N>(g.m + tb * N, ms);
+        qload<R, N, N>(g.Pf + tb * N * N, Ps);
+        qload<R, P, N>(g.Cs + (tb + B) * P * N, C);   // C_T, the extra entry
+        vstore<R, N>(g.ms + tb * N, ms, active);
+        qstore<R, N, N>(g.Ps + tb * N * N, Ps, active);
+        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, C, LR, active)) st |= ST_NONPD_SMOOTHED;
+    }
+    for (int t = T - 2; t >= 0; --t) {
+        const long tb = (long)t * B + b;
+        R m[N], mn[N];
+        QM<R, N, N> Pf, Pn, An;
+        gload<R, N>(g.m + tb * N, m);
+        qload<R, N, N>(g.Pf + tb * N * N, Pf);
+        gload<R, N>(g.mn + tb * N, mn);
+        qload<R, N, N>(g.Pn + tb * N * N, Pn);
+        qload<R, N, N>(g.As + (tb + B) * N * N, An);
+        qload<R, P, N>(g.Cs + tb * P * N, C);
+
+        QM<R, N, N> Pi, W, J, D, T1;
+        if (!qspd_inverse<R, N>(Pn, Pi)) st |= ST_NONPD_PREDICTED;
+        mm<R, N, N, N, true, false, 0>(An, Pi, W);    // An^T Pi
+        mm<R, N, N, N, false, false, 0>(Pf, W, J);    // J = Pf An^T Pi
+        R d[N];
+        KV_UNROLL
+        for (int i = 0; i < N; ++i) d[i] = ms[i] - mn[i];
+        qblend<R, N, N>(R(1), Ps, R(-1), Pn, D);
+        vcopy<R, N>(m, ms);
+        mv<R, N, N, false, 1>(J, d, ms);
+        mm<R, N, N, N, false, false, 0>(J, D, T1);
+        qcopy<R, N, N>(Pf, Ps);
+        mm<R, N, N, N, false, true, 1>(T1, J, Ps);
+        if (g.symmetrize) qsymmetrize<R, N>(Ps);
+        vstore<R, N>(g.ms + tb * N, ms, active);
+        qstore<R, N, N>(g.Ps + tb * N * N, Ps, active);
+        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, C, LR, active)) st |= ST_NONPD_SMOOTHED;
+    }
+    if (st && active && g.status && qlane() == 0) atomicOr(g.status, st);
+}
+
+// acc_LR: P*P running sum of the gradient of LR, replicated in the quad (or null)
+template <typename R, int N, int P>
+KQ_DEV void qsmooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, const R* mean,
+                                 const QM<R, N, N>& cov, const QM<R, P, N>& C, R* msb,
+                                 QM<R, N, N>& Psb, QM<R, P, N>& Cb, R* acc_LR, R on) {
+    const SmoothFwdArgs<R>& f = g.f;
+    R zb[N], ab[P];
+    gload_or_zero<R, N>(g.g_zs, tb * N, zb);
+    gload_or_zero<R, P>(g.g_ares, tb * P, ab);
+    qzero<R, P, N>(Cb);
+    R L[N * N], e[N];
+    if (f.eps_s && (g.g_ares || g.g_zs)) {
+        R F[N * N];
+        qgather<R, N, N>(cov, F);
+        cholesky<R, N>(F, L);
+        gload<R, N>(f.eps_s + tb * N, e);
+    }
+    if (g.g_ares) {
+        R z[N];
+        vcopy<R, N>(mean, z);
+        if (f.eps_s) gemv<R, N, N, false, 1>(L, e, z);
+        qouter_add<R, P, N>(R(1), ab, z, Cb);
+        mv<R, N, P, true, 1>(C, ab, zb);              // zb += C^T ab
+        if (f.eps_o && acc_LR) {
+            R eo[P];
+            gload<R, P>(f.eps_o + tb * P, eo);
+            outer_add<R, P, P>(on, ab, eo, acc_LR);
+        }
+    }
+    if (g.g_ares || g.g_zs) {
+        vadd<R, N>(zb, msb);
+        if (f.eps_s) {
+            R Lb[N * N], Sadd[N * N];
+            vzero<R, N * N>(Lb);
+            vzero<R, N * N>(Sadd);
+            outer_add<R, N, N>(R(1), zb, e, Lb);
+            cholesky_adjoint_add<R, N>(L, Lb, Sadd);
+            QM<R, N, N> Sq;
+            qscatter<R, N, N>(Sadd, Sq);
+            qadd<R, N, N>(Sq, Psb);
+        }
+    }
+}
+
+template <typename R, int N, int P>
+KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, R* acc_LR) {
+    const SmoothFwdArgs<R>& f = g.f;
+    const long B = f.B;
+    const int T = f.T;
+    const R on = active ? R(1) : R(0);
+    R msb[N];
+    QM<R, N, N> Psb;
+    vzero<R, N>(msb);
+    qzero<R, N, N>(Psb);
+    {
+        QM<R, N, N> z1;
+        QM<R, P, N> z2;
+        R zv[N];
+        qzero<R, N, N>(z1);
+        qzero<R, P, N>(z2);
+        vzero<R, N>(zv);
+        qstore<R, N, N>(g.d_As + (long)b * N * N, z1, active);                   // A_0
+        qstore<R, N, N>(g.d_As + ((long)T * B + b) * N * N, z1, active);         // A_T
+        qstore<R, P, N>(g.d_Cs + ((long)(T - 1) * B + b) * P * N, z2, active);   // C_{T-1}
+        vstore<R, N>(g.d_mn + ((long)(T - 1) * B + b) * N, zv, active);
+        qstore<R, N, N>(g.d_Pn + ((long)(T - 1) * B + b) * N * N, z1, active);
+    }
+    for (int t = 0; t < T - 1; ++t) {
+        const long tb = (long)t * B + b;
+        R m[N], mn[N], ms1[N], ms0[N];
+        QM<R, N, N> Pf, Pn, An, Ps1, Ps0;
+        QM<R, P, N> C;
+        gload<R, N>(f.m + tb * N, m);
+        qload<R, N, N>(f.Pf + tb * N * N, Pf);
+        gload<R, N>(f.mn + tb * N, mn);
+        qload<R, N, N>(f.Pn + tb * N * N, Pn);
+        qload<R, N, N>(f.As + (tb + B) * N * N, An);
+        qload<R, P, N>(f.Cs + tb * P * N, C);
+        gload<R, N>(f.ms + (tb + B) * N, ms1);
+        qload<R, N, N>(f.Ps + (tb + B) * N * N, Ps1);
+        gload<R, N>(f.ms + tb * N, ms0);
+        qload<R, N, N>(f.Ps + tb * N * N, Ps0);
+
+        if (g.g_ms) {
+            KV_UNROLL
+            for (int i = 0; i < N; ++i) msb[i] += g.g_ms[tb * N + i];
+        }
+        if (g.g_Ps) {
+            QM<R, N, N> gp;
+            qload<R, N, N>(g.g_Ps + tb * N * N, gp);
+            qadd<R, N, N>(gp, Psb);
+        }
+        QM<R, P, N> Cb;
+        qsmooth_emit_adjoint<R, N, P>(g, tb, ms0, Ps0, C, msb, Psb, Cb, acc_LR, on);
+        qstore<R, P, N>(g.d_Cs + tb * P * N, Cb, active);
+        if (t < g.burn_in) {
+            vzero<R, N>(msb);
+            qzero<R, N, N>(Psb);
+        }
+
+        // recompute the step
+        QM<R, N, N> Pi, W, J, D;
+        R d[N];
+        qspd_inverse<R, N>(Pn, Pi);
+        mm<R, N, N, N, true, false, 0>(An, Pi, W);
+        mm<R, N, N, N, false, false, 0>(Pf, W, J);
+        KV_UNROLL
+        for (int i = 0; i < N; ++i) d[i] = ms1[i] - mn[i];
+        qblend<R, N, N>(R(1), Ps1, R(-1), Pn, D);
+
+        if (f.symmetrize) qsymmetrize<R, N>(Psb);   // H
+        vstore<R, N>(g.d_m + tb * N, msb, active);
+        QM<R, N, N> Pfb;
+        qcopy<R, N, N>(Psb, Pfb);
+        // Jbar = msb d^T + H J D^T + H^T J D
+        QM<R, N, N> Jb, T1;
+        qzero<R, N, N>(Jb);
+        qouter_add<R, N, N>(R(1), msb, d, Jb);
+        mm<R, N, N, N, false, true, 0>(J, D, T1);         // J D^T
+        mm<R, N, N, N, false, false, 1>(Psb, T1, Jb);
+        mm<R, N, N, N, false, false, 0>(J, D, T1);        // J D
+        mm<R, N, N, N, true, false, 1>(Psb, T1, Jb);
+        // dbar = J^T msb ; Dbar = J^T H J
+        R db[N];
+        QM<R, N, N> Db;
+        mv<R, N, N, true, 0>(J, msb, db);
+        mm<R, N, N, N, true, false, 0>(J, Psb, T1);
+        mm<R, N, N, N, false, false, 0>(T1, J, Db);
+        // J = Pf W ; W = An^T Pi
+        mm<R, N, N, N, false, true, 1>(Jb, W, Pfb);       // Pfb += Jb W^T
+        QM<R, N, N> Wb, Anb, Pib, Pnb;
+        mm<R, N, N, N, true, false, 0>(Pf, Jb, Wb);       // Pf^T Jb
+        mm<R, N, N, N, false, true, 0>(Pi, Wb, Anb);      // Anb = Pi Wb^T
+        mm<R, N, N, N, false, false, 0>(An, Wb, Pib);     // Pib = An Wb
+        // Pnb = -Db - Pi^T Pib Pi^T
+        mm<R, N, N, N, true, false, 0>(Pi, Pib, T1);
+        mm<R, N, N, N, false, true, 0>(T1, Pi, Pnb);
+        qblend<R, N, N>(R(-1), Pnb, R(-1), Db, Pnb);
+        R mnb[N];
+        KV_UNROLL
+        for (int i = 0; i < N; ++i) mnb[i] = -db[i];
+        qstore<R, N, N>(g.d_P + tb * N * N, Pfb, active);
+        vstore<R, N>(g.d_mn + tb * N, mnb, active);
+        qstore<R, N, N>(g.d_Pn + tb * N * N, Pnb, active);
+        qstore<R, N, N>(g.d_As + (tb + B) * N * N, Anb, active);
+        // carry to step t+1
+        vcopy<R, N>(db, msb);
+        qcopy<R, N, N>(Db, Psb);
+    }
+    {
+        const long tb = (long)(T - 1) * B + b;
+        R ms0[N];
+        QM<R, N, N> Ps0;
+        QM<R, P, N> C, Cb;
+        gload<R, N>(f.ms + tb * N, ms0);
+        qload<R, N, N>(f.Ps + tb * N * N, Ps0);
+        qload<R, P, N>(f.Cs + (tb + B) * P * N, C);
+        if (g.g_ms) {
+            KV_UNROLL
+            for (int i = 0; i < N; ++i) msb[i] += g.g_ms[tb * N + i];
+        }
+        if (g.g_Ps) {
+            QM<R, N, N> gp;
+            qload<R, N, N>(g.g_Ps + tb * N * N, gp);
+            qadd<R, N, N>(gp, Psb);
+        }
+        qsmooth_emit_adjoint<R, N, P>(g, tb, ms0, Ps0, C, msb, Psb, Cb, acc_LR, on);
+        qstore<R, P, N>(g.d_Cs + (tb + B) * P * N, Cb, active);
+        vstore<R, N>(g.d_m + tb * N, msb, active);
+        qstore<R, N, N>(g.d_P + tb * N * N, Psb, active);
+    }
+}
+
 // Sum over the 16 sequences of the wavefront (lanes with equal q), result valid in
 // the first quad.
 template <typename R>

@@ -77,6 +77,31 @@ __global__ void __launch_bounds__(SEQ_BLOCK) filter_backward_kernel(FilterBwdArg
 }
 
 template <typename R, int N, int P>
+__global__ void __launch_bounds__(SEQ_BLOCK) smooth_forward_quad_kernel(SmoothFwdArgs<R> g) {
+    const int b = blockIdx.x * QUAD_SEQS + (threadIdx.x >> 2);
+    const bool active = b < g.B;
+    quad::smooth_forward_quad<R, N, P>(g, active ? b : g.B - 1, active);
+}
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(SEQ_BLOCK) smooth_backward_quad_kernel(SmoothBwdArgs<R> g) {
+    constexpr int LEN = P * P;
+    const int b = blockIdx.x * QUAD_SEQS + (threadIdx.x >> 2);
+    const bool active = b < g.f.B;
+    R acc[LEN];     // replicated in the four lanes of a quad
+    vzero<R, LEN>(acc);
+    quad::smooth_backward_quad<R, N, P>(g, active ? b : g.f.B - 1, active, acc);
+    if (g.partial) {
+        const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+        for (int e = 0; e < LEN; ++e) {
+            const R s = quad::sum_over_quads(acc[e]);
+            if (lane == 0) g.partial[(long)blockIdx.x * LEN + e] = s;
+        }
+    }
+}
+
+template <typename R, int N, int P>
 __global__ void __launch_bounds__(SEQ_BLOCK) smooth_forward_kernel(SmoothFwdArgs<R> g) {
     const int b = blockIdx.x * SEQ_BLOCK + threadIdx.x;
     if (b < g.B) smooth_forward_sequence<R, N, P>(g, b);
@@ -183,6 +208,13 @@ int run_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws,
 template <typename R, int N, int P>
 int run_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
     SmoothFwdArgs<R> g = make_args<R>(d, io);
+    if constexpr (N <= 4 && P <= 4) {
+        if (use_quad<N, P>(d->B)) {
+            hipLaunchKernelGGL((smooth_forward_quad_kernel<R, N, P>), dim3(quad_blocks(d->B)),
+                               dim3(SEQ_BLOCK), 0, s, g);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL((smooth_forward_kernel<R, N, P>), dim3(seq_blocks(d->B)), dim3(SEQ_BLOCK), 0,
                        s, g);
     return launch_status();
@@ -191,9 +223,19 @@ int run_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_
 template <typename R, int N, int P>
 int run_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
                         hipStream_t s) {
+    SmoothBwdArgs<R> g = make_args<R>(d, io, ws);
+    if constexpr (N <= 4 && P <= 4) {
+        if (use_quad<N, P>(d->B)) {
+            const long qrows = quad_blocks(d->B);
+            if (io->d_LR && ws_bytes < (size_t)qrows * P * P * sizeof(R)) return KVAE_E_WORKSPACE;
+            hipLaunchKernelGGL((smooth_backward_quad_kernel<R, N, P>), dim3(qrows), dim3(SEQ_BLOCK),
+                               0, s, g);
+            if (io->d_LR) reduce_smooth_grads<R, P>(io, ws, qrows, s);
+            return launch_status();
+        }
+    }
     const long rows = seq_rows(d->B);
     if (io->d_LR && ws_bytes < (size_t)rows * P * P * sizeof(R)) return KVAE_E_WORKSPACE;
-    SmoothBwdArgs<R> g = make_args<R>(d, io, ws);
     hipLaunchKernelGGL((smooth_backward_kernel<R, N, P>), dim3(seq_blocks(d->B)), dim3(SEQ_BLOCK),
                        0, s, g);
     if (io->d_LR) reduce_smooth_grads<R, P>(io, ws, rows, s);
@@ -277,7 +319,7 @@ size_t kvae_workspace_bytes(const kvae_dims* d, int op) {
             return (size_t)(n <= 4 && p <= 4 ? quad_blocks(d->B) : seq_rows(d->B)) *
                    (K * n * n + K * p * n + n * n + p * p) * el;
         case KVAE_OP_SMOOTH_BWD:
-            return (size_t)seq_rows(d->B) * (p * p) * el;
+            return (size_t)(n <= 4 && p <= 4 ? quad_blocks(d->B) : seq_rows(d->B)) * (p * p) * el;
         case KVAE_OP_ELBO_BWD:
             return (size_t)pair_rows((long)d->T * d->B) * (n * n + p * p + n + n * n) * el;
         default:
