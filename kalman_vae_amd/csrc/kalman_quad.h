@@ -661,27 +661,30 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
 // ---------------------------------------------------------------------------
 template <typename R, int N, int P>
 KQ_DEV bool qsmooth_emit(const SmoothFwdArgs<R>& g, long tb, const R* mean, const QM<R, N, N>& cov,
-                         const QM<R, P, N>& C, const R* LR, bool active) {
+                         const QM<R, P, N>& C, const R* LR, const R* es, const R* eo,
+                         bool active) {
     bool ok = true;
     R z[N], ar[P];
     vcopy<R, N>(mean, z);
     if (g.eps_s) {
-        R F[N * N], L[N * N], e[N];
+        R F[N * N], L[N * N];
         qgather<R, N, N>(cov, F);
         ok = cholesky<R, N>(F, L);
-        gload<R, N>(g.eps_s + tb * N, e);
-        gemv<R, N, N, false, 1>(L, e, z);
+        gemv<R, N, N, false, 1>(L, es, z);
     }
     mv<R, P, N, false, 0>(C, z, ar);
-    if (g.eps_o) {
-        R e[P];
-        gload<R, P>(g.eps_o + tb * P, e);
-        gemv<R, P, P, false, 1>(LR, e, ar);
-    }
+    if (g.eps_o) gemv<R, P, P, false, 1>(LR, eo, ar);
     vstore<R, N>(g.zs + tb * N, z, active);
     vstore<R, P>(g.ares + tb * P, ar, active);
     return ok;
 }
+
+template <typename R, int N, int P>
+struct QSmoothIn {
+    R m[N], mn[N], es[N], eo[P];
+    QM<R, N, N> Pf, Pn, An;
+    QM<R, P, N> C;
+};
 
 template <typename R, int N, int P>
 KQ_DEV void smooth_forward_quad(const SmoothFwdArgs<R>& g, int b, bool active) {
@@ -696,76 +699,91 @@ KQ_DEV void smooth_forward_quad(const SmoothFwdArgs<R>& g, int b, bool active) {
     int st = 0;
     R ms[N];
     QM<R, N, N> Ps;
-    QM<R, P, N> C;
-    {
-        const long tb = (long)(T - 1) * B + b;
-        gload<R, N>(g.m + tb * N, ms);
-        qload<R, N, N>(g.Pf + tb * N * N, Ps);
-        qload<R, P, N>(g.Cs + (tb + B) * P * N, C);   // C_T, the extra entry
-        vstore<R, N>(g.ms + tb * N, ms, active);
-        qstore<R, N, N>(g.Ps + tb * N * N, Ps, active);
-        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, C, LR, active)) st |= ST_NONPD_SMOOTHED;
-    }
-    for (int t = T - 2; t >= 0; --t) {
+    // the inputs of a step do not depend on the recursion: step t-1's are loaded
+    // while step t computes (two buffers used in turn)
+    auto load_noise = [&](long tb, R* es, R* eo) {
+        gload_or_zero<R, N>(g.eps_s, tb * N, es);
+        gload_or_zero<R, P>(g.eps_o, tb * P, eo);
+    };
+    auto load_inputs = [&](int t, QSmoothIn<R, N, P>& in) {
         const long tb = (long)t * B + b;
-        R m[N], mn[N];
-        QM<R, N, N> Pf, Pn, An;
-        gload<R, N>(g.m + tb * N, m);
-        qload<R, N, N>(g.Pf + tb * N * N, Pf);
-        gload<R, N>(g.mn + tb * N, mn);
-        qload<R, N, N>(g.Pn + tb * N * N, Pn);
-        qload<R, N, N>(g.As + (tb + B) * N * N, An);
-        qload<R, P, N>(g.Cs + tb * P * N, C);
-
+        gload<R, N>(g.m + tb * N, in.m);
+        qload<R, N, N>(g.Pf + tb * N * N, in.Pf);
+        gload<R, N>(g.mn + tb * N, in.mn);
+        qload<R, N, N>(g.Pn + tb * N * N, in.Pn);
+        qload<R, N, N>(g.As + (tb + B) * N * N, in.An);
+        qload<R, P, N>(g.Cs + tb * P * N, in.C);
+        load_noise(tb, in.es, in.eo);
+    };
+    auto step = [&](int t, const QSmoothIn<R, N, P>& in) {
+        const long tb = (long)t * B + b;
         QM<R, N, N> Pi, W, J, D, T1;
-        if (!qspd_inverse<R, N>(Pn, Pi)) st |= ST_NONPD_PREDICTED;
-        mm<R, N, N, N, true, false, 0>(An, Pi, W);    // An^T Pi
-        mm<R, N, N, N, false, false, 0>(Pf, W, J);    // J = Pf An^T Pi
+        if (!qspd_inverse<R, N>(in.Pn, Pi)) st |= ST_NONPD_PREDICTED;
+        mm<R, N, N, N, true, false, 0>(in.An, Pi, W);    // An^T Pi
+        mm<R, N, N, N, false, false, 0>(in.Pf, W, J);    // J = Pf An^T Pi
         R d[N];
         KV_UNROLL
-        for (int i = 0; i < N; ++i) d[i] = ms[i] - mn[i];
-        qblend<R, N, N>(R(1), Ps, R(-1), Pn, D);
-        vcopy<R, N>(m, ms);
+        for (int i = 0; i < N; ++i) d[i] = ms[i] - in.mn[i];
+        qblend<R, N, N>(R(1), Ps, R(-1), in.Pn, D);
+        vcopy<R, N>(in.m, ms);
         mv<R, N, N, false, 1>(J, d, ms);
         mm<R, N, N, N, false, false, 0>(J, D, T1);
-        qcopy<R, N, N>(Pf, Ps);
+        qcopy<R, N, N>(in.Pf, Ps);
         mm<R, N, N, N, false, true, 1>(T1, J, Ps);
         if (g.symmetrize) qsymmetrize<R, N>(Ps);
         vstore<R, N>(g.ms + tb * N, ms, active);
         qstore<R, N, N>(g.Ps + tb * N * N, Ps, active);
-        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, C, LR, active)) st |= ST_NONPD_SMOOTHED;
+        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, in.C, LR, in.es, in.eo, active))
+            st |= ST_NONPD_SMOOTHED;
+    };
+    QSmoothIn<R, N, P> in0, in1;
+    if (T >= 2) load_inputs(T - 2, in0);
+    {
+        const long tb = (long)(T - 1) * B + b;
+        QM<R, P, N> C;
+        R es[N], eo[P];
+        gload<R, N>(g.m + tb * N, ms);
+        qload<R, N, N>(g.Pf + tb * N * N, Ps);
+        qload<R, P, N>(g.Cs + (tb + B) * P * N, C);   // C_T, the extra entry
+        load_noise(tb, es, eo);
+        vstore<R, N>(g.ms + tb * N, ms, active);
+        qstore<R, N, N>(g.Ps + tb * N * N, Ps, active);
+        if (!qsmooth_emit<R, N, P>(g, tb, ms, Ps, C, LR, es, eo, active)) st |= ST_NONPD_SMOOTHED;
+    }
+    for (int t = T - 2; t >= 0; t -= 2) {
+        if (t >= 1) load_inputs(t - 1, in1);
+        step(t, in0);
+        if (t >= 1) {
+            if (t >= 2) load_inputs(t - 2, in0);
+            step(t - 1, in1);
+        }
     }
     if (st && active && g.status && qlane() == 0) atomicOr(g.status, st);
 }
 
 // acc_LR: P*P running sum of the gradient of LR, replicated in the quad (or null)
 template <typename R, int N, int P>
-KQ_DEV void qsmooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, const R* mean,
-                                 const QM<R, N, N>& cov, const QM<R, P, N>& C, R* msb,
-                                 QM<R, N, N>& Psb, QM<R, P, N>& Cb, R* acc_LR, R on) {
+KQ_DEV void qsmooth_emit_adjoint(const SmoothBwdArgs<R>& g, const R* mean, const QM<R, N, N>& cov,
+                                 const QM<R, P, N>& C, const R* zb_in, const R* ab, const R* es,
+                                 const R* eo, R* msb, QM<R, N, N>& Psb, QM<R, P, N>& Cb,
+                                 R* acc_LR, R on) {
     const SmoothFwdArgs<R>& f = g.f;
-    R zb[N], ab[P];
-    gload_or_zero<R, N>(g.g_zs, tb * N, zb);
-    gload_or_zero<R, P>(g.g_ares, tb * P, ab);
+    R zb[N];
+    vcopy<R, N>(zb_in, zb);
     qzero<R, P, N>(Cb);
-    R L[N * N], e[N];
+    R L[N * N];
     if (f.eps_s && (g.g_ares || g.g_zs)) {
         R F[N * N];
         qgather<R, N, N>(cov, F);
         cholesky<R, N>(F, L);
-        gload<R, N>(f.eps_s + tb * N, e);
     }
     if (g.g_ares) {
         R z[N];
         vcopy<R, N>(mean, z);
-        if (f.eps_s) gemv<R, N, N, false, 1>(L, e, z);
+        if (f.eps_s) gemv<R, N, N, false, 1>(L, es, z);
         qouter_add<R, P, N>(R(1), ab, z, Cb);
         mv<R, N, P, true, 1>(C, ab, zb);              // zb += C^T ab
-        if (f.eps_o && acc_LR) {
-            R eo[P];
-            gload<R, P>(f.eps_o + tb * P, eo);
-            outer_add<R, P, P>(on, ab, eo, acc_LR);
-        }
+        if (f.eps_o && acc_LR) outer_add<R, P, P>(on, ab, eo, acc_LR);
     }
     if (g.g_ares || g.g_zs) {
         vadd<R, N>(zb, msb);
@@ -773,7 +791,7 @@ KQ_DEV void qsmooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, const R* me
             R Lb[N * N], Sadd[N * N];
             vzero<R, N * N>(Lb);
             vzero<R, N * N>(Sadd);
-            outer_add<R, N, N>(R(1), zb, e, Lb);
+            outer_add<R, N, N>(R(1), zb, es, Lb);
             cholesky_adjoint_add<R, N>(L, Lb, Sadd);
             QM<R, N, N> Sq;
             qscatter<R, N, N>(Sadd, Sq);
@@ -781,6 +799,14 @@ KQ_DEV void qsmooth_emit_adjoint(const SmoothBwdArgs<R>& g, long tb, const R* me
         }
     }
 }
+
+// what one backward step of the smoother reads from global memory
+template <typename R, int N, int P>
+struct QSmoothBwdIn {
+    R m[N], mn[N], ms1[N], ms0[N], gms[N], zb[N], ab[P], es[N], eo[P];
+    QM<R, N, N> Pf, Pn, An, Ps1, Ps0, gPs;
+    QM<R, P, N> C;
+};
 
 template <typename R, int N, int P>
 KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, R* acc_LR) {
@@ -805,33 +831,35 @@ KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, 
         vstore<R, N>(g.d_mn + ((long)(T - 1) * B + b) * N, zv, active);
         qstore<R, N, N>(g.d_Pn + ((long)(T - 1) * B + b) * N * N, z1, active);
     }
-    for (int t = 0; t < T - 1; ++t) {
+    auto load_emit = [&](long tb, QSmoothBwdIn<R, N, P>& in) {
+        gload<R, N>(f.ms + tb * N, in.ms0);
+        qload<R, N, N>(f.Ps + tb * N * N, in.Ps0);
+        gload_or_zero<R, N>(g.g_ms, tb * N, in.gms);
+        qload_or_zero<R, N, N>(g.g_Ps, tb * N * N, in.gPs);
+        gload_or_zero<R, N>(g.g_zs, tb * N, in.zb);
+        gload_or_zero<R, P>(g.g_ares, tb * P, in.ab);
+        gload_or_zero<R, N>(f.eps_s, tb * N, in.es);
+        gload_or_zero<R, P>(f.eps_o, tb * P, in.eo);
+    };
+    auto load_inputs = [&](int t, QSmoothBwdIn<R, N, P>& in) {
         const long tb = (long)t * B + b;
-        R m[N], mn[N], ms1[N], ms0[N];
-        QM<R, N, N> Pf, Pn, An, Ps1, Ps0;
-        QM<R, P, N> C;
-        gload<R, N>(f.m + tb * N, m);
-        qload<R, N, N>(f.Pf + tb * N * N, Pf);
-        gload<R, N>(f.mn + tb * N, mn);
-        qload<R, N, N>(f.Pn + tb * N * N, Pn);
-        qload<R, N, N>(f.As + (tb + B) * N * N, An);
-        qload<R, P, N>(f.Cs + tb * P * N, C);
-        gload<R, N>(f.ms + (tb + B) * N, ms1);
-        qload<R, N, N>(f.Ps + (tb + B) * N * N, Ps1);
-        gload<R, N>(f.ms + tb * N, ms0);
-        qload<R, N, N>(f.Ps + tb * N * N, Ps0);
-
-        if (g.g_ms) {
-            KV_UNROLL
-            for (int i = 0; i < N; ++i) msb[i] += g.g_ms[tb * N + i];
-        }
-        if (g.g_Ps) {
-            QM<R, N, N> gp;
-            qload<R, N, N>(g.g_Ps + tb * N * N, gp);
-            qadd<R, N, N>(gp, Psb);
-        }
+        gload<R, N>(f.m + tb * N, in.m);
+        qload<R, N, N>(f.Pf + tb * N * N, in.Pf);
+        gload<R, N>(f.mn + tb * N, in.mn);
+        qload<R, N, N>(f.Pn + tb * N * N, in.Pn);
+        qload<R, N, N>(f.As + (tb + B) * N * N, in.An);
+        qload<R, P, N>(f.Cs + tb * P * N, in.C);
+        gload<R, N>(f.ms + (tb + B) * N, in.ms1);
+        qload<R, N, N>(f.Ps + (tb + B) * N * N, in.Ps1);
+        load_emit(tb, in);
+    };
+    auto step = [&](int t, const QSmoothBwdIn<R, N, P>& in) {
+        const long tb = (long)t * B + b;
+        vadd<R, N>(in.gms, msb);
+        qadd<R, N, N>(in.gPs, Psb);
         QM<R, P, N> Cb;
-        qsmooth_emit_adjoint<R, N, P>(g, tb, ms0, Ps0, C, msb, Psb, Cb, acc_LR, on);
+        qsmooth_emit_adjoint<R, N, P>(g, in.ms0, in.Ps0, in.C, in.zb, in.ab, in.es, in.eo, msb, Psb,
+                                      Cb, acc_LR, on);
         qstore<R, P, N>(g.d_Cs + tb * P * N, Cb, active);
         if (t < g.burn_in) {
             vzero<R, N>(msb);
@@ -841,12 +869,12 @@ KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, 
         // recompute the step
         QM<R, N, N> Pi, W, J, D;
         R d[N];
-        qspd_inverse<R, N>(Pn, Pi);
-        mm<R, N, N, N, true, false, 0>(An, Pi, W);
-        mm<R, N, N, N, false, false, 0>(Pf, W, J);
+        qspd_inverse<R, N>(in.Pn, Pi);
+        mm<R, N, N, N, true, false, 0>(in.An, Pi, W);
+        mm<R, N, N, N, false, false, 0>(in.Pf, W, J);
         KV_UNROLL
-        for (int i = 0; i < N; ++i) d[i] = ms1[i] - mn[i];
-        qblend<R, N, N>(R(1), Ps1, R(-1), Pn, D);
+        for (int i = 0; i < N; ++i) d[i] = in.ms1[i] - in.mn[i];
+        qblend<R, N, N>(R(1), in.Ps1, R(-1), in.Pn, D);
 
         if (f.symmetrize) qsymmetrize<R, N>(Psb);   // H
         vstore<R, N>(g.d_m + tb * N, msb, active);
@@ -869,9 +897,9 @@ KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, 
         // J = Pf W ; W = An^T Pi
         mm<R, N, N, N, false, true, 1>(Jb, W, Pfb);       // Pfb += Jb W^T
         QM<R, N, N> Wb, Anb, Pib, Pnb;
-        mm<R, N, N, N, true, false, 0>(Pf, Jb, Wb);       // Pf^T Jb
+        mm<R, N, N, N, true, false, 0>(in.Pf, Jb, Wb);    // Pf^T Jb
         mm<R, N, N, N, false, true, 0>(Pi, Wb, Anb);      // Anb = Pi Wb^T
-        mm<R, N, N, N, false, false, 0>(An, Wb, Pib);     // Pib = An Wb
+        mm<R, N, N, N, false, false, 0>(in.An, Wb, Pib);  // Pib = An Wb
         // Pnb = -Db - Pi^T Pib Pi^T
         mm<R, N, N, N, true, false, 0>(Pi, Pib, T1);
         mm<R, N, N, N, false, true, 0>(T1, Pi, Pnb);
@@ -886,25 +914,28 @@ KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, 
         // carry to step t+1
         vcopy<R, N>(db, msb);
         qcopy<R, N, N>(Db, Psb);
+    };
+    QSmoothBwdIn<R, N, P> in0, in1;
+    if (T >= 2) load_inputs(0, in0);
+    for (int t = 0; t < T - 1; t += 2) {
+        if (t + 1 < T - 1) load_inputs(t + 1, in1);
+        step(t, in0);
+        if (t + 1 < T - 1) {
+            if (t + 2 < T - 1) load_inputs(t + 2, in0);
+            step(t + 1, in1);
+        }
     }
     {
+        // last step: smoothed == filtered, emission uses C_T
         const long tb = (long)(T - 1) * B + b;
-        R ms0[N];
-        QM<R, N, N> Ps0;
+        QSmoothBwdIn<R, N, P> in;
         QM<R, P, N> C, Cb;
-        gload<R, N>(f.ms + tb * N, ms0);
-        qload<R, N, N>(f.Ps + tb * N * N, Ps0);
+        load_emit(tb, in);
         qload<R, P, N>(f.Cs + (tb + B) * P * N, C);
-        if (g.g_ms) {
-            KV_UNROLL
-            for (int i = 0; i < N; ++i) msb[i] += g.g_ms[tb * N + i];
-        }
-        if (g.g_Ps) {
-            QM<R, N, N> gp;
-            qload<R, N, N>(g.g_Ps + tb * N * N, gp);
-            qadd<R, N, N>(gp, Psb);
-        }
-        qsmooth_emit_adjoint<R, N, P>(g, tb, ms0, Ps0, C, msb, Psb, Cb, acc_LR, on);
+        vadd<R, N>(in.gms, msb);
+        qadd<R, N, N>(in.gPs, Psb);
+        qsmooth_emit_adjoint<R, N, P>(g, in.ms0, in.Ps0, C, in.zb, in.ab, in.es, in.eo, msb, Psb, Cb,
+                                      acc_LR, on);
         qstore<R, P, N>(g.d_Cs + (tb + B) * P * N, Cb, active);
         vstore<R, N>(g.d_m + tb * N, msb, active);
         qstore<R, N, N>(g.d_P + tb * N * N, Psb, active);

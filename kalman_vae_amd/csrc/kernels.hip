@@ -151,15 +151,18 @@ inline long seq_blocks(long B) { return (B + SEQ_BLOCK - 1) / SEQ_BLOCK; }
 inline long quad_blocks(long B) { return (B + QUAD_SEQS - 1) / QUAD_SEQS; }
 
 // Four lanes per sequence while one lane per sequence would leave SIMDs without a
-// wavefront (1024 SIMDs); KVAE_SEQ_LANES=1|4 forces one form (tests, timing).
+// wavefront.  Measured crossover (MI355X, n=4, p=2): the quad kernels are 1.5-2x
+// faster up to 16k sequences and slower from 64k on, except the filter forward
+// kernel, which is faster at every size.  KVAE_SEQ_LANES=1|4 forces one form
+// (tests, timing).
 template <int N, int P>
-inline bool use_quad(long B) {
+inline bool use_quad(long B, bool at_any_size = false) {
     if (N > 4 || P > 4) return false;
     const char* e = getenv("KVAE_SEQ_LANES");
     const int forced = e ? atoi(e) : 0;
     if (forced == 1) return false;
     if (forced == 4) return true;
-    return seq_blocks(B) < 1024;
+    return at_any_size || B < 32768;
 }
 inline long seq_rows(long B) { return seq_blocks(B) * (SEQ_BLOCK / WAVE); }
 inline long pair_blocks(long TB) { return (TB + PAIR_BLOCK - 1) / PAIR_BLOCK; }
@@ -170,7 +173,7 @@ template <typename R, int N, int P, int K>
 int run_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
     FilterFwdArgs<R> g = make_args<R>(d, io);
     if constexpr (N <= 4 && P <= 4) {
-        if (use_quad<N, P>(d->B)) {
+        if (use_quad<N, P>(d->B, true)) {
             hipLaunchKernelGGL((filter_forward_quad_kernel<R, N, P, K>), dim3(quad_blocks(d->B)),
                                dim3(SEQ_BLOCK), 0, s, g);
             return launch_status();
