@@ -18,7 +18,7 @@ for path in sys.argv[6:]:
         name = r["Kernel_Name"]
         if "kvae::" not in name:
             continue
-        short = name.split("kvae::")[1].split("<")[0].replace("_kernel", "").replace("wave_", "")
+        short = name.split("kvae::")[1].split("<")[0].replace("_kernel", "").replace("wave_", "").replace("_quad", "")
         vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("| kernel | FETCH_SIZE kB (raw) | WRITE_SIZE kB | algorithmic read+write MB | "
       "counted MB (fetch x2 + write) | counted / algorithmic |")
