@@ -33,32 +33,33 @@ def kalman_elbo(
     ssm = state_space_model
     T, B = as_.shape[:2]
     _validate_shape(as_, (T, B, ssm.a_dim), "as_")
-    (filter_means, filter_covariances, filter_next_means, filter_next_covariances,
-     mat_As, mat_Cs, filter_as, weights) = ssm.kalman_filter(
-        as_, sample_control=sample_control, observation_mask=observation_mask,
-        learn_weight_model=learn_weight_model, symmetrize_covariance=symmetrize_covariance,
-        burn_in=burn_in)
-    means, covariances, zs, as_resampled = ssm.kalman_smooth(
-        as_, filter_means=filter_means, filter_covariances=filter_covariances,
-        filter_next_means=filter_next_means, filter_next_covariances=filter_next_covariances,
-        mat_As=mat_As, mat_Cs=mat_Cs, sample_control=sample_control,
-        symmetrize_covariance=symmetrize_covariance, burn_in=burn_in)
+    with ssm.cached_matrices():     # Q, R and chol(R) are formed once for the whole step
+        (filter_means, filter_covariances, filter_next_means, filter_next_covariances,
+         mat_As, mat_Cs, filter_as, weights) = ssm.kalman_filter(
+            as_, sample_control=sample_control, observation_mask=observation_mask,
+            learn_weight_model=learn_weight_model, symmetrize_covariance=symmetrize_covariance,
+            burn_in=burn_in)
+        means, covariances, zs, as_resampled = ssm.kalman_smooth(
+            as_, filter_means=filter_means, filter_covariances=filter_covariances,
+            filter_next_means=filter_next_means, filter_next_covariances=filter_next_covariances,
+            mat_As=mat_As, mat_Cs=mat_Cs, sample_control=sample_control,
+            symmetrize_covariance=symmetrize_covariance, burn_in=burn_in)
 
-    # zs_distrib.rsample(): one (T,B,n) standard-normal draw, always sampled
-    eps = _standard_normal((T, B, ssm.z_dim), dtype=as_.dtype, device=as_.device)
-    obs, trans, post, _ = F.kalman_elbo_terms(
-        as_, means, covariances, mat_As, mat_Cs, ssm.mat_Q, ssm.mat_R,
-        ssm.initial_state_mean, ssm.initial_state_covariance, eps)
+        # zs_distrib.rsample(): one (T,B,n) standard-normal draw, always sampled
+        eps = _standard_normal((T, B, ssm.z_dim), dtype=as_.dtype, device=as_.device)
+        obs, trans, post, _ = F.kalman_elbo_terms(
+            as_, means, covariances, mat_As, mat_Cs, ssm.mat_Q, ssm.mat_R,
+            ssm.initial_state_mean, ssm.initial_state_covariance, eps)
     if ssm.check_numerics:
         F.raise_on_status(as_.device)
-    # aggregate(v) (kvae/misc.py:21-41) is a constant times the total of v; the total
-    # is a deterministic tree sum on the HIP library
-    scale = aggregate_weights(T, B, sequence_operation, batch_operation)
-    agg = lambda v: scale * F.total_sum(v)
-    w_obs = kalman_weight * agg(obs)
-    w_trans = kalman_weight * agg(trans)
-    w_post = -kalman_weight * agg(post)
-    objective = w_obs + w_trans + w_post
+    # aggregate(v) (kvae/misc.py:21-41) is a constant times the total of v; the three
+    # totals are one deterministic tree sum on the HIP library, the weights
+    # (kalman_weight, and the minus sign of the posterior term, kalman_vae.py:244-260)
+    # one multiplication by a constant vector
+    c = kalman_weight * aggregate_weights(T, B, sequence_operation, batch_operation)
+    weighted = F.term_totals(obs, trans, post) * F.constant_vector((c, c, -c), obs)
+    w_obs, w_trans, w_post = weighted[0], weighted[1], weighted[2]
+    objective = weighted.sum()
     info = {
         "kalman_weight": kalman_weight,
         "kalman_observation_log_likelihood": w_obs,

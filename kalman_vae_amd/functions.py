@@ -126,6 +126,52 @@ class TotalSumFunction(torch.autograd.Function):
         return g.expand(ctx.shape)
 
 
+class TermTotalsFunction(torch.autograd.Function):
+    """(obs, trans, post), each (T,B) -> their three totals as a (3,) tensor: the
+    reduction inside ``aggregate`` (kvae/misc.py:21-41) for all three ELBO terms
+    in one launch when the terms are adjacent in memory (as kalman_elbo_terms
+    returns them)."""
+
+    @staticmethod
+    def forward(ctx, obs, trans, post):
+        capi.require_gpu(obs, trans, post)
+        lib = capi.load()
+        n = obs.numel()
+        step = n * obs.element_size()
+        adjacent = (obs.is_contiguous() and trans.is_contiguous() and post.is_contiguous()
+                    and trans.data_ptr() == obs.data_ptr() + step
+                    and post.data_ptr() == obs.data_ptr() + 2 * step)
+        src = obs if adjacent else torch.stack([obs, trans, post])
+        out = torch.empty(3, dtype=obs.dtype, device=obs.device)
+        scratch = torch.empty(max(1, lib.kvae_vector_sum_scratch_elems(3, n)), dtype=obs.dtype,
+                              device=obs.device)
+        capi.check(lib.kvae_vector_sum(3, n, capi.dtype_code(obs.dtype), src.data_ptr(),
+                                       scratch.data_ptr(), out.data_ptr(),
+                                       capi.current_stream_ptr()))
+        ctx.shape = obs.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        full = g.view(3, *([1] * len(ctx.shape))).expand(3, *ctx.shape).contiguous()
+        return full[0], full[1], full[2]
+
+
+def term_totals(obs, trans, post):
+    return TermTotalsFunction.apply(obs, trans, post)
+
+
+_constant_vectors = {}
+
+
+def constant_vector(values, like):
+    """A small constant tensor kept on the device (no host-to-device copy per step)."""
+    key = (tuple(float(v) for v in values), like.dtype, like.device.type, like.device.index)
+    if key not in _constant_vectors:
+        _constant_vectors[key] = torch.tensor(key[0], dtype=like.dtype, device=like.device)
+    return _constant_vectors[key]
+
+
 def total_sum(v):
     return TotalSumFunction.apply(v)
 
@@ -254,7 +300,10 @@ class KalmanElboFunction(torch.autograd.Function):
         p = a.shape[2]
         dims = _dims(T, B, n, p, _any_K(n, p), a.dtype, True, 0)
         new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
-        obs, trans, post, z = new(T, B), new(T, B), new(T, B), new(T, B, n)
+        # the three terms live in one (3,T,B) buffer so that they can be totalled by
+        # one launch (term_totals)
+        terms, z = new(3, T, B), new(T, B, n)
+        obs, trans, post = terms[0], terms[1], terms[2]
         io = capi.fill(capi.ElboFwd(), a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs,
                        Q=Q, R=R, m0=m0, P0=P0, eps=eps, obs=obs, trans=trans, post=post, z=z,
                        status=status_word(a.device))

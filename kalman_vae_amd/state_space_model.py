@@ -21,6 +21,8 @@ How the work is split:
 """
 from typing import Optional
 
+import contextlib
+
 import torch
 import torch.nn as nn
 from torch.distributions.utils import _standard_normal
@@ -80,6 +82,7 @@ class StateSpaceModel(nn.Module):
         self.weight_model = make_weight_model(dynamics_parameter_network, a_dim, K,
                                               hidden_dim, num_layers)
         # behaviour switches that have no counterpart in the reference
+        self._matrix_cache = None   # see cached_matrices()
         self.rng_parity = True      # draw noise exactly like the reference does
         self.check_numerics = True  # raise on a non-positive-definite covariance (host sync)
 
@@ -97,11 +100,42 @@ class StateSpaceModel(nn.Module):
 
     @property
     def mat_Q(self):
-        return self._gated(self._mat_Q_L @ self._mat_Q_L.T + self._z_eye * self.Q_reg, True)
+        return self._noise_covariance("Q", self._mat_Q_L, self._z_eye, self.Q_reg)
 
     @property
     def mat_R(self):
-        return self._gated(self._mat_R_L @ self._mat_R_L.T + self._a_eye * self.R_reg, True)
+        return self._noise_covariance("R", self._mat_R_L, self._a_eye, self.R_reg)
+
+    def _noise_covariance(self, key, factor, eye, reg):
+        cache = self._matrix_cache
+        if cache is not None and key in cache:
+            return cache[key]
+        value = self._gated(factor @ factor.T + eye * reg, True)
+        if cache is not None:
+            cache[key] = value
+        return value
+
+    @contextlib.contextmanager
+    def cached_matrices(self):
+        """Within the block ``mat_Q`` / ``mat_R`` (and the Cholesky factor of R) are
+        formed once and reused: the reference rebuilds them on every property
+        access (state_space_model.py:112-146), a handful of tiny kernels each time.
+        Only valid while the parameters are not modified, i.e. inside one step."""
+        outer = self._matrix_cache
+        self._matrix_cache = {} if outer is None else outer
+        try:
+            yield self
+        finally:
+            self._matrix_cache = outer
+
+    def _cholesky_R(self):
+        cache = self._matrix_cache
+        if cache is not None and "L_R" in cache:
+            return cache["L_R"]
+        value = F.cholesky_factor(self.mat_R)
+        if cache is not None:
+            cache["L_R"] = value
+        return value
 
     @property
     def mat_A_K(self):
@@ -270,7 +304,7 @@ class StateSpaceModel(nn.Module):
             if obs_noise:
                 eps_obs = self._draw((T, B, self.a_dim), as_)
         if obs_noise:
-            L_R = F.cholesky_factor(self.mat_R)
+            L_R = self._cholesky_R()
         out = F.kalman_smooth_steps(
             filter_means, filter_covariances, filter_next_means, filter_next_covariances,
             mat_As, mat_Cs, LR=L_R, eps_state=eps_state, eps_obs=eps_obs,
