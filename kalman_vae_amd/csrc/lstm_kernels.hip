@@ -634,48 +634,110 @@ __device__ __forceinline__ void mfma16_k512(f32x4 (&acc)[2], const float* g_tile
     }
 }
 
+// Two products that share the A operand: accA += g_tile * WA[:, unit], accB += g_tile * WB[:, unit]
+// (one LDS read feeds four MFMAs on four independent accumulators).
+constexpr int GC16D = GC16 / 2;
+struct WChunk2 {
+    float2 va[GC16D], vb[GC16D];
+    __device__ __forceinline__ void load(const float* __restrict__ wa, const float* __restrict__ wb,
+                                         int kk0) {
+#pragma unroll
+        for (int u = 0; u < GC16D; ++u) {
+            va[u] = *reinterpret_cast<const float2*>(wa + (long)(4 * (kk0 + u)) * PH);
+            vb[u] = *reinterpret_cast<const float2*>(wb + (long)(4 * (kk0 + u)) * PH);
+        }
+    }
+    __device__ __forceinline__ void apply(f32x4 (&accA)[2], f32x4 (&accB)[2], const float* a_row,
+                                          int kk0) const {
+#pragma unroll
+        for (int u = 0; u < GC16D; ++u) {
+            const float a = a_row[4 * (kk0 + u)];
+            accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, va[u].x, accA[0], 0, 0, 0);
+            accA[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, va[u].y, accA[1], 0, 0, 0);
+            accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb[u].x, accB[0], 0, 0, 0);
+            accB[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb[u].y, accB[1], 0, 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ void mfma16_k512_dual(f32x4 (&accA)[2], f32x4 (&accB)[2],
+                                                 const float* g_tile, const float* __restrict__ WA,
+                                                 const float* __restrict__ WB, int u0) {
+    static_assert((PG4 / 4) % (2 * GC16D) == 0, "chunk pairs must tile K");
+    const int lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    const long off = u0 + 2 * c + (long)s * PH;
+    const float *wa = WA + off, *wb = WB + off;
+    const float* a_row = g_tile + c * LDG16 + s;
+    WChunk2 b0, b1;
+    b0.load(wa, wb, 0);
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < PG4 / 4; kk0 += 2 * GC16D) {
+        b1.load(wa, wb, kk0 + GC16D);
+        b0.apply(accA, accB, a_row, kk0);
+        if (kk0 + 2 * GC16D < PG4 / 4) b0.load(wa, wb, kk0 + 2 * GC16D);
+        b1.apply(accA, accB, a_row, kk0 + GC16D);
+    }
+}
+
+// What the cell adjoint of one layer and step reads from global memory for this
+// lane's 4 rows x 2 units.  None of it depends on the recurrence, so it is loaded
+// one phase ahead, while the previous phase's MFMAs run.
+struct CellIn {
+    float2 ig[4], fg[4], gg[4], og[4], cc[4], cp[4];
+    __device__ __forceinline__ void load(int t, int B, int r0, int ub, int s,
+                                         const float* __restrict__ gates,
+                                         const float* __restrict__ cg) {
+        const long BH = (long)B * PH, BG = (long)B * PG4;
+        const float2 z = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            ig[i] = fg[i] = gg[i] = og[i] = cc[i] = cp[i] = z;
+            if (row < B) {
+                const float* gr = gates + t * BG + (long)row * PG4 + ub;
+                ig[i] = *reinterpret_cast<const float2*>(gr);
+                fg[i] = *reinterpret_cast<const float2*>(gr + PH);
+                gg[i] = *reinterpret_cast<const float2*>(gr + 2 * PH);
+                og[i] = *reinterpret_cast<const float2*>(gr + 3 * PH);
+                const long o = (long)row * PH + ub;
+                cc[i] = *reinterpret_cast<const float2*>(cg + t * BH + o);
+                if (t > 0) cp[i] = *reinterpret_cast<const float2*>(cg + (t - 1) * BH + o);
+            }
+        }
+    }
+};
+
 // element-wise LSTM cell adjoint for this lane's 4 rows x 2 units; dh is the
 // total gradient w.r.t. h_t.  Writes dG (global, step t) and the LDS A-operand
 // tile, and returns the gate gradients in dgt[row][gate] (zero for rows >= B).
-__device__ __forceinline__ void cell_backward16(const float (&dh)[4][2], float (&dc)[4][2], int t,
-                                                int B, int r0, int ub, int s,
-                                                const float* __restrict__ gates,
-                                                const float* __restrict__ cg,
-                                                float* __restrict__ dG, float* g_tile,
+__device__ __forceinline__ void cell_backward16(const float (&dh)[4][2], float (&dc)[4][2],
+                                                const CellIn& in, int t, int B, int r0, int ub,
+                                                int s, float* __restrict__ dG, float* g_tile,
                                                 float2 (&dgt)[4][4]) {
-    const long BH = (long)B * PH, BG = (long)B * PG4;
+    const long BG = (long)B * PG4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lr = 4 * s + i, row = r0 + lr;
-        float2 di = {0.f, 0.f}, df = {0.f, 0.f}, dg = {0.f, 0.f}, dout = {0.f, 0.f};
+        float2 di, df, dg, dout;
+        {
+            const float tc = tanhf_(in.cc[i].x);
+            const float dct = dh[i][0] * in.og[i].x * (1.f - tc * tc) + dc[i][0];
+            di.x = dct * in.gg[i].x * in.ig[i].x * (1.f - in.ig[i].x);
+            df.x = dct * in.cp[i].x * in.fg[i].x * (1.f - in.fg[i].x);
+            dg.x = dct * in.ig[i].x * (1.f - in.gg[i].x * in.gg[i].x);
+            dout.x = dh[i][0] * tc * in.og[i].x * (1.f - in.og[i].x);
+            dc[i][0] = dct * in.fg[i].x;
+        }
+        {
+            const float tc = tanhf_(in.cc[i].y);
+            const float dct = dh[i][1] * in.og[i].y * (1.f - tc * tc) + dc[i][1];
+            di.y = dct * in.gg[i].y * in.ig[i].y * (1.f - in.ig[i].y);
+            df.y = dct * in.cp[i].y * in.fg[i].y * (1.f - in.fg[i].y);
+            dg.y = dct * in.ig[i].y * (1.f - in.gg[i].y * in.gg[i].y);
+            dout.y = dh[i][1] * tc * in.og[i].y * (1.f - in.og[i].y);
+            dc[i][1] = dct * in.fg[i].y;
+        }
         if (row < B) {
-            const float* gr = gates + t * BG + (long)row * PG4 + ub;
-            const float2 ig = *reinterpret_cast<const float2*>(gr);
-            const float2 fg = *reinterpret_cast<const float2*>(gr + PH);
-            const float2 gg = *reinterpret_cast<const float2*>(gr + 2 * PH);
-            const float2 og = *reinterpret_cast<const float2*>(gr + 3 * PH);
-            const long o = (long)row * PH + ub;
-            const float2 cc = *reinterpret_cast<const float2*>(cg + t * BH + o);
-            float2 cp = {0.f, 0.f};
-            if (t > 0) cp = *reinterpret_cast<const float2*>(cg + (t - 1) * BH + o);
-            {
-                const float tc = tanhf_(cc.x);
-                const float dct = dh[i][0] * og.x * (1.f - tc * tc) + dc[i][0];
-                di.x = dct * gg.x * ig.x * (1.f - ig.x);
-                df.x = dct * cp.x * fg.x * (1.f - fg.x);
-                dg.x = dct * ig.x * (1.f - gg.x * gg.x);
-                dout.x = dh[i][0] * tc * og.x * (1.f - og.x);
-                dc[i][0] = dct * fg.x;
-            }
-            {
-                const float tc = tanhf_(cc.y);
-                const float dct = dh[i][1] * og.y * (1.f - tc * tc) + dc[i][1];
-                di.y = dct * gg.y * ig.y * (1.f - ig.y);
-                df.y = dct * cp.y * fg.y * (1.f - fg.y);
-                dg.y = dct * ig.y * (1.f - gg.y * gg.y);
-                dout.y = dh[i][1] * tc * og.y * (1.f - og.y);
-                dc[i][1] = dct * fg.y;
-            }
             float* d = dG + t * BG + (long)row * PG4 + ub;
             *reinterpret_cast<float2*>(d) = di;
             *reinterpret_cast<float2*>(d + PH) = df;
@@ -699,6 +761,13 @@ __device__ __forceinline__ void cell_backward16(const float (&dh)[4][2], float (
 // library GEMM would be badly shaped: dx = dG0 * Wih0 (T,B,P), and per-workgroup
 // partial sums over (t, rows) of dG0, dG1 (bias gradients) and dG0^T x (layer-0
 // input weights), written to partial[blockIdx.x][ 4H | 4H | 4H*P ].
+//
+// Per step: (A) cell adjoint of layer 1 -> tile1; barrier; (B) tile1 x [Whh1 | Wih1]
+// in one pass; (C) cell adjoint of layer 0 -> tile0; barrier; (D) tile0 x Whh0.
+// The two tiles are separate so that two barriers per step order every LDS reuse:
+// tile1 is rewritten in (A) of the next step, after the barrier of (C) that every
+// wavefront reaches only after its reads in (B); tile0 is rewritten in (C) of the
+// next step, after the barrier of (A) that follows every wavefront's reads in (D).
 template <int P>
 __global__ void __launch_bounds__(256)
 lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
@@ -710,7 +779,8 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
                                    const float* __restrict__ Whh1, float* __restrict__ dG0,
                                    float* __restrict__ dG1, float* __restrict__ dx,
                                    float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float g_tile[16 * LDG16];
+    __shared__ __attribute__((aligned(16))) float tile1[16 * LDG16];
+    __shared__ __attribute__((aligned(16))) float tile0[16 * LDG16];
     __shared__ float dx_part[4][16][P];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
     const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * c;
@@ -735,18 +805,29 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
             }
         }
     }
-    for (int t = T - 1; t >= 0; --t) {
-        float dh[4][2];
-        float2 dgt[4][4];
+    auto load_gh = [&](int t, float2 (&gh)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 4 * s + i;
-            float2 g = {0.f, 0.f};
-            if (row < B) g = *reinterpret_cast<const float2*>(g_h1 + t * BH + (long)row * PH + ub);
-            dh[i][0] = dh1rec[0][i] + g.x;
-            dh[i][1] = dh1rec[1][i] + g.y;
+            gh[i] = make_float2(0.f, 0.f);
+            if (row < B) gh[i] = *reinterpret_cast<const float2*>(g_h1 + t * BH + (long)row * PH + ub);
         }
-        cell_backward16(dh, dc1, t, B, r0, ub, s, gates1, c1g, dG1, g_tile, dgt);
+    };
+    CellIn in1, in0;
+    float2 gh[4];
+    float xv[4][P];
+    in1.load(T - 1, B, r0, ub, s, gates1, c1g);
+    load_gh(T - 1, gh);
+    for (int t = T - 1; t >= 0; --t) {
+        float dh[4][2];
+        float2 dgt[4][4];
+        // ---- (A) layer 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dh[i][0] = dh1rec[0][i] + gh[i].x;
+            dh[i][1] = dh1rec[1][i] + gh[i].y;
+        }
+        cell_backward16(dh, dc1, in1, t, B, r0, ub, s, dG1, tile1, dgt);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -755,38 +836,40 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
                 sb1[g][1] += dgt[i][g].y;
             }
         }
-        __syncthreads();
-        if (t > 0) {
+        // inputs of (C), in flight during (B)
+        in0.load(t, B, r0, ub, s, gates0, c0g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dh1rec[0][i] = dh1rec[1][i] = 0.f;
-            mfma16_k512(dh1rec, g_tile, Whh1, u0);
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+#pragma unroll
+            for (int q = 0; q < P; ++q) xv[i][q] = row < B ? x[((long)t * B + row) * P + q] : 0.f;
         }
-        mfma16_k512(dh0rec, g_tile, Wih1, u0);   // adds layer 1's input path to layer 0's recurrent one
+        __syncthreads();
+        // ---- (B) dh1rec = tile1 x Whh1 (recurrent path of layer 1, for step t-1);
+        //          dh0rec += tile1 x Wih1 (layer 1's input path into layer 0's h_t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh1rec[0][i] = dh1rec[1][i] = 0.f;
+        mfma16_k512_dual(dh1rec, dh0rec, tile1, Whh1, Wih1, u0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dh[i][0] = dh0rec[0][i];
             dh[i][1] = dh0rec[1][i];
         }
-        __syncthreads();
-        cell_backward16(dh, dc0, t, B, r0, ub, s, gates0, c0g, dG0, g_tile, dgt);
-        // layer-0 side products of the gate gradients
+        // ---- (C) layer 0
+        cell_backward16(dh, dc0, in0, t, B, r0, ub, s, dG0, tile0, dgt);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = r0 + 4 * s + i;
-            float xv[P], dxp[P];
+            float dxp[P];
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xv[q] = row < B ? x[((long)t * B + row) * P + q] : 0.f;
-                dxp[q] = 0.f;
-            }
+            for (int q = 0; q < P; ++q) dxp[q] = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sb0[g][0] += dgt[i][g].x;
                 sb0[g][1] += dgt[i][g].y;
 #pragma unroll
                 for (int q = 0; q < P; ++q) {
-                    sw[g][0][q] += dgt[i][g].x * xv[q];
-                    sw[g][1][q] += dgt[i][g].y * xv[q];
+                    sw[g][0][q] += dgt[i][g].x * xv[i][q];
+                    sw[g][1][q] += dgt[i][g].y * xv[i][q];
                     dxp[q] += dgt[i][g].x * wx[g][0][q] + dgt[i][g].y * wx[g][1][q];
                 }
             }
@@ -798,6 +881,11 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
                 if (c == 0) dx_part[wave][4 * s + i][q] = v;
             }
         }
+        // inputs of the next step's (A), in flight during (D)
+        if (t > 0) {
+            in1.load(t - 1, B, r0, ub, s, gates1, c1g);
+            load_gh(t - 1, gh);
+        }
         __syncthreads();
         if (threadIdx.x < 16 * P) {
             const int lr = threadIdx.x / P, q = threadIdx.x % P;
@@ -805,10 +893,10 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
                 dx[((long)t * B + r0 + lr) * P + q] = dx_part[0][lr][q] + dx_part[1][lr][q] +
                                                       dx_part[2][lr][q] + dx_part[3][lr][q];
         }
+        // ---- (D) dh0rec = tile0 x Whh0 (recurrent path of layer 0, for step t-1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dh0rec[0][i] = dh0rec[1][i] = 0.f;
-        if (t > 0) mfma16_k512(dh0rec, g_tile, Whh0, u0);
-        __syncthreads();
+        if (t > 0) mfma16_k512(dh0rec, tile0, Whh0, u0);
     }
     // sum the per-lane column accumulators over the four row groups (lane bits 4, 5)
     float* part = partial + (long)blockIdx.x * (PG4 * (2 + P));

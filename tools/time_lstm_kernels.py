@@ -57,7 +57,7 @@ def lstm_kernels(B):
                                            whh1.data_ptr(), dG0.data_ptr(), dG1.data_ptr(),
                                            dx.data_ptr(), part.data_ptr(), st))
     flops = 2.0 * T * B * 4 * H * (H + 2 * H)      # recurrent + layer-1 input products
-    for rows in (16, 32):
+    for rows in ((16,) if os.environ.get("KVAE_ONLY16") else (16, 32)):
         os.environ["KVAE_LSTM_TILE_ROWS"] = str(rows)
         tf, tb = timed(fwd), timed(bwd)
         print(f"B={B} rows={rows}: fwd {tf:8.1f} us ({flops / tf * 1e-6:6.1f} TFLOP/s)  "
