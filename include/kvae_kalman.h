@@ -231,7 +231,10 @@ int kvae_lstm_layer_backward(int T, int B, int H, const void *gates, const void 
  * registers, weights streamed from L2.
  * forward: x (T,B,P), Wih0 (4H,P), b0 = b_ih0 + b_hh0 (4H), Whh0T / Wih1T /
  *   Whh1T: the (4H,H) matrices transposed to (H,4H), b1 = b_ih1 + b_hh1; outputs
- *   gates0/1 (T,B,4H) activated, h0/1 and c0/1 (T,B,H).
+ *   gates0/1 (T,B,4H) activated (both may be null when no backward will follow),
+ *   h0/1 and c0/1 (T,B,H).  h_init / c_init: (2,B,H) state to start from, both null
+ *   for the zero state - the cached state LSTMModel carries between calls
+ *   (dynamics_parameter_network.py:28-33, 53), used by the step-by-step masked filter.
  * backward: g_h1 (T,B,H) gradient w.r.t. the top layer's h; Wih0 (4H,P); Whh0,
  *   Wih1, Whh1 as stored (4H,H).  Outputs: dG0, dG1 (T,B,4H), the gate
  *   pre-activation gradients (operands of the caller's three time-batched
@@ -242,7 +245,7 @@ int kvae_lstm_layer_backward(int T, int B, int H, const void *gates, const void 
 int kvae_lstm2_forward(int T, int B, int P, const void *x, const void *Wih0, const void *b0,
                        const void *Whh0T, const void *Wih1T, const void *Whh1T, const void *b1,
                        void *gates0, void *h0, void *c0, void *gates1, void *h1, void *c1,
-                       void *stream);
+                       const void *h_init, const void *c_init, void *stream);
 int kvae_lstm2_backward_blocks(int B);
 int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, const void *gates0,
                         const void *c0, const void *gates1, const void *c1, const void *Wih0,

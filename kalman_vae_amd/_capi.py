@@ -149,7 +149,7 @@ def load():
     lib.kvae_lstm_layer_forward.restype = C.c_int
     lib.kvae_lstm_layer_backward.argtypes = [C.c_int] * 3 + [_vp] * 7
     lib.kvae_lstm_layer_backward.restype = C.c_int
-    lib.kvae_lstm2_forward.argtypes = [C.c_int] * 3 + [_vp] * 14
+    lib.kvae_lstm2_forward.argtypes = [C.c_int] * 3 + [_vp] * 16
     lib.kvae_lstm2_forward.restype = C.c_int
     lib.kvae_lstm2_backward.argtypes = [C.c_int] * 3 + [_vp] * 15
     lib.kvae_lstm2_backward_blocks.argtypes = [C.c_int]

@@ -364,11 +364,13 @@ __device__ __forceinline__ void cell_epilogue(const f32x16 (&acc)[4], float (&c)
             const long o = (long)row * PH + u;
             h_t[o] = h;
             c_t[o] = c[r];
-            float* gr = gates_t + (long)row * PG4 + u;
-            gr[0] = ig;
-            gr[PH] = fg;
-            gr[2 * PH] = gg;
-            gr[3 * PH] = og;
+            if (gates_t) {
+                float* gr = gates_t + (long)row * PG4 + u;
+                gr[0] = ig;
+                gr[PH] = fg;
+                gr[2 * PH] = gg;
+                gr[3 * PH] = og;
+            }
         }
     }
 }
@@ -385,7 +387,9 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
                                 const float* __restrict__ b1,                    // (4H)
                                 float* __restrict__ gates0, float* __restrict__ h0,
                                 float* __restrict__ c0g, float* __restrict__ gates1,
-                                float* __restrict__ h1, float* __restrict__ c1g) {
+                                float* __restrict__ h1, float* __restrict__ c1g,
+                                const float* __restrict__ h_init,   // (2,B,H) or null
+                                const float* __restrict__ c_init) { // (2,B,H) or null
     __shared__ float hbuf0[2][32 * PLDA];
     __shared__ float hbuf1[2][32 * PLDA];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
@@ -394,7 +398,20 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
 
     float c0[16], c1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+        c0[r] = c1[r] = 0.f;
+        const int lr = acc_row(r, hh), row = r0 + lr;
+        if (c_init && row < B) {
+            c0[r] = c_init[(long)row * PH + u];
+            c1[r] = c_init[BH + (long)row * PH + u];
+        }
+        if (h_init) {   // h of "step -1" goes where step 0 looks for it
+            hbuf0[1][lr * PLDA + u] = row < B ? h_init[(long)row * PH + u] : 0.f;
+            hbuf1[1][lr * PLDA + u] = row < B ? h_init[BH + (long)row * PH + u] : 0.f;
+        }
+    }
+    if (h_init) __syncthreads();
+    const bool carried = h_init != nullptr;
     // this lane's layer-0 input weights and biases (4 gates x P)
     float wx[4][P], bias0[4], bias1[4];
 #pragma unroll
@@ -421,8 +438,8 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
                 acc[g][r] = s;
             }
         }
-        if (t > 0) mfma_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
-        cell_epilogue(acc, c0, B, r0, u, hh, gates0 + t * BG, h0 + t * BH, c0g + t * BH,
+        if (t > 0 || carried) mfma_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
+        cell_epilogue(acc, c0, B, r0, u, hh, gates0 ? gates0 + t * BG : nullptr, h0 + t * BH, c0g + t * BH,
                       hbuf0[t & 1]);
         __syncthreads();
         // ---- layer 1: input product with h0_t, recurrent product with h1_{t-1}
@@ -432,8 +449,8 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
             for (int r = 0; r < 16; ++r) acc[g][r] = bias1[g];
         }
         mfma_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0);
-        if (t > 0) mfma_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
-        cell_epilogue(acc, c1, B, r0, u, hh, gates1 + t * BG, h1 + t * BH, c1g + t * BH,
+        if (t > 0 || carried) mfma_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
+        cell_epilogue(acc, c1, B, r0, u, hh, gates1 ? gates1 + t * BG : nullptr, h1 + t * BH, c1g + t * BH,
                       hbuf1[t & 1]);
         // hbuf1[t&1] is first read after the barrier of step t+1; hbuf0[(t+1)&1] was
         // last read before the barrier above
@@ -520,11 +537,13 @@ __device__ __forceinline__ void cell_epilogue16(const f32x4 (&acc)[4][2], float 
             const long o = (long)row * PH + ub;
             *reinterpret_cast<float2*>(h_t + o) = hv;
             *reinterpret_cast<float2*>(c_t + o) = cv;
-            float* gr = gates_t + (long)row * PG4 + ub;
-            *reinterpret_cast<float2*>(gr) = ig;
-            *reinterpret_cast<float2*>(gr + PH) = fg;
-            *reinterpret_cast<float2*>(gr + 2 * PH) = gg;
-            *reinterpret_cast<float2*>(gr + 3 * PH) = og;
+            if (gates_t) {
+                float* gr = gates_t + (long)row * PG4 + ub;
+                *reinterpret_cast<float2*>(gr) = ig;
+                *reinterpret_cast<float2*>(gr + PH) = fg;
+                *reinterpret_cast<float2*>(gr + 2 * PH) = gg;
+                *reinterpret_cast<float2*>(gr + 3 * PH) = og;
+            }
         }
     }
 }
@@ -538,7 +557,9 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
                                   const float* __restrict__ Whh1T, const float* __restrict__ b1,
                                   float* __restrict__ gates0, float* __restrict__ h0,
                                   float* __restrict__ c0g, float* __restrict__ gates1,
-                                  float* __restrict__ h1, float* __restrict__ c1g) {
+                                  float* __restrict__ h1, float* __restrict__ c1g,
+                                  const float* __restrict__ h_init,   // (2,B,H) or null
+                                  const float* __restrict__ c_init) { // (2,B,H) or null
     __shared__ __attribute__((aligned(16))) float hbuf0[2][16 * PLDA16];
     __shared__ __attribute__((aligned(16))) float hbuf1[2][16 * PLDA16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
@@ -547,7 +568,27 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
 
     float c0[4][2], c1[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c0[i][0] = c0[i][1] = c1[i][0] = c1[i][1] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        c0[i][0] = c0[i][1] = c1[i][0] = c1[i][1] = 0.f;
+        const int lr = 4 * s + i, row = r0 + lr;
+        if (c_init && row < B) {
+            const float2 a = *reinterpret_cast<const float2*>(c_init + (long)row * PH + ub);
+            const float2 b = *reinterpret_cast<const float2*>(c_init + BH + (long)row * PH + ub);
+            c0[i][0] = a.x; c0[i][1] = a.y;
+            c1[i][0] = b.x; c1[i][1] = b.y;
+        }
+        if (h_init) {   // h of "step -1" goes where step 0 looks for it
+            float2 a = {0.f, 0.f}, b = {0.f, 0.f};
+            if (row < B) {
+                a = *reinterpret_cast<const float2*>(h_init + (long)row * PH + ub);
+                b = *reinterpret_cast<const float2*>(h_init + BH + (long)row * PH + ub);
+            }
+            *reinterpret_cast<float2*>(&hbuf0[1][lr * PLDA16 + ub]) = a;
+            *reinterpret_cast<float2*>(&hbuf1[1][lr * PLDA16 + ub]) = b;
+        }
+    }
+    if (h_init) __syncthreads();
+    const bool carried = h_init != nullptr;
     float wx[4][2][P], bias0[4][2], bias1[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -578,8 +619,8 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
                 }
             }
         }
-        if (t > 0) mfma16_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
-        cell_epilogue16(acc, c0, B, r0, ub, s, gates0 + t * BG, h0 + t * BH, c0g + t * BH,
+        if (t > 0 || carried) mfma16_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
+        cell_epilogue16(acc, c0, B, r0, ub, s, gates0 ? gates0 + t * BG : nullptr, h0 + t * BH, c0g + t * BH,
                         hbuf0[t & 1]);
         __syncthreads();
 #pragma unroll
@@ -591,8 +632,8 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
             }
         }
         mfma16_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0);
-        if (t > 0) mfma16_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
-        cell_epilogue16(acc, c1, B, r0, ub, s, gates1 + t * BG, h1 + t * BH, c1g + t * BH,
+        if (t > 0 || carried) mfma16_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
+        cell_epilogue16(acc, c1, B, r0, ub, s, gates1 ? gates1 + t * BG : nullptr, h1 + t * BH, c1g + t * BH,
                         hbuf1[t & 1]);
         // the barrier of step t+1 orders these h1 writes before their first read,
         // and the barrier above ordered the last reads of hbuf0[(t+1)&1] before now
@@ -945,9 +986,10 @@ extern "C" {
 int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, const void* b0,
                        const void* Whh0T, const void* Wih1T, const void* Whh1T, const void* b1,
                        void* gates0, void* h0, void* c0, void* gates1, void* h1, void* c1,
-                       void* stream) {
-    if (T < 1 || B < 1 || !x || !Wih0 || !b0 || !Whh0T || !Wih1T || !Whh1T || !b1 || !gates0 ||
-        !h0 || !c0 || !gates1 || !h1 || !c1)
+                       const void* h_init, const void* c_init, void* stream) {
+    if (T < 1 || B < 1 || !x || !Wih0 || !b0 || !Whh0T || !Wih1T || !Whh1T || !b1 || !h0 || !c0 ||
+        !h1 || !c1 || (gates0 == nullptr) != (gates1 == nullptr) ||
+        (h_init == nullptr) != (c_init == nullptr))
         return KVAE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool rows16 = kvae::lstm2_use_16_row_tiles(B);
@@ -955,7 +997,8 @@ int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, con
 #define KVAE_L2F_ARGS                                                                           \
     T, B, (const float*)x, (const float*)Wih0, (const float*)b0, (const float*)Whh0T,           \
         (const float*)Wih1T, (const float*)Whh1T, (const float*)b1, (float*)gates0, (float*)h0, \
-        (float*)c0, (float*)gates1, (float*)h1, (float*)c1
+        (float*)c0, (float*)gates1, (float*)h1, (float*)c1, (const float*)h_init,               \
+        (const float*)c_init
 #define KVAE_L2F(P_)                                                                            \
     if (rows16)                                                                                 \
         hipLaunchKernelGGL(kvae::lstm2_persistent_forward16_kernel<P_>, grid, dim3(256), 0, s,  \

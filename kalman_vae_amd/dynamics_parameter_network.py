@@ -48,6 +48,12 @@ class LSTMModel(nn.Module):
             h, hidden = lstm_function.fused_lstm(x, self.lstm)
             self.hidden = (hidden[0].detach(), hidden[1].detach())
             return lstm_function.softmax_head(h, self.linear)
+        if (self.use_hip_recurrence and not torch.is_grad_enabled()
+                and lstm_function.persistent_supported(x, self.lstm)):
+            # inference from the carried state (the step-by-step masked filter): the
+            # persistent kernel continues from self.hidden, no library RNN call
+            h, self.hidden = lstm_function.lstm2_nograd(x, self.lstm, self.hidden)
+            return lstm_function.softmax_head(h, self.linear)
         if self.hidden is None:
             self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
         h, self.hidden = self.lstm(x, self.hidden)

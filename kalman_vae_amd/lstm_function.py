@@ -126,7 +126,7 @@ class FusedLSTM2Function(torch.autograd.Function):
         capi.check(lib.kvae_lstm2_forward(
             T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), gates0.data_ptr(),
             h0.data_ptr(), c0.data_ptr(), gates1.data_ptr(), h1.data_ptr(), c1.data_ptr(),
-            capi.current_stream_ptr()))
+            None, None, capi.current_stream_ptr()))
         ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
         h_n, c_n = torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]])
         ctx.mark_non_differentiable(h_n, c_n)
@@ -204,6 +204,37 @@ def softmax_head(h, linear):
     if head_supported(h, linear):
         return SoftmaxHeadFunction.apply(h, linear.weight, linear.bias)
     return torch.softmax(linear(h), dim=-1)
+
+
+def persistent_supported(x, lstm):
+    return (supported(x, lstm.hidden_size) and lstm.num_layers == 2 and lstm.hidden_size == 128
+            and x.shape[2] <= 4 and not lstm.bidirectional)
+
+
+@torch.no_grad()
+def lstm2_nograd(x, lstm, hidden=None):
+    """Inference through the persistent two-layer kernel from a carried state:
+    x (T,B,in), hidden = (h (2,B,H), c (2,B,H)) or None.  Returns (top-layer h
+    (T,B,H), (h_n, c_n)).  This is what the step-by-step (masked) filter calls with
+    T = 1 at every step; no gates are stored and no autograd graph is recorded."""
+    lib = capi.load()
+    T, B, P = x.shape
+    H = 128
+    x = x.contiguous()
+    new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
+    h0, c0, h1, c1 = new(T, B, H), new(T, B, H), new(T, B, H), new(T, B, H)
+    w = lambda n: getattr(lstm, n)
+    keep = (w("weight_ih_l0").contiguous(), w("bias_ih_l0") + w("bias_hh_l0"),
+            w("weight_hh_l0").t().contiguous(), w("weight_ih_l1").t().contiguous(),
+            w("weight_hh_l1").t().contiguous(), w("bias_ih_l1") + w("bias_hh_l1"))
+    h_init = c_init = None
+    if hidden is not None:
+        h_init, c_init = hidden[0].contiguous(), hidden[1].contiguous()
+    capi.check(lib.kvae_lstm2_forward(
+        T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), None, h0.data_ptr(), c0.data_ptr(),
+        None, h1.data_ptr(), c1.data_ptr(), capi.ptr(h_init), capi.ptr(c_init),
+        capi.current_stream_ptr()))
+    return h1, (torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]]))
 
 
 def fused_lstm(x, lstm):

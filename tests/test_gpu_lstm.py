@@ -76,3 +76,26 @@ def test_softmax_head_matches_torch(R_shape, H, K):
     assert rel_err(out, ref) < 1e-5
     bad = [(n, rel_err(a, b)) for n, a, b in zip(("h", "W", "b"), g, gref) if not rel_err(a, b) < 1e-4]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,rows", [(50, 16), (50, 32), (1, 16), (300, 32)])
+def test_weight_model_stepwise_inference_on_hip_equals_torch(B, rows, monkeypatch):
+    """Step-by-step inference (the masked filter's call pattern) through the
+    persistent kernel with carried state == torch.nn.LSTM fed the same steps."""
+    from kalman_vae_amd.dynamics_parameter_network import LSTMModel
+    monkeypatch.setenv("KVAE_LSTM_TILE_ROWS", str(rows))
+    torch.manual_seed(B)
+    dev = torch.device("cuda:0")
+    net = LSTMModel(2, 3, 128, 2).to(dev).eval()
+    x = torch.randn(9, B, 2, device=dev)
+    with torch.no_grad():
+        net.clear_hidden_state()
+        hip = torch.cat([net(x[t:t + 1]) for t in range(5)] + [net(x[5:9])])   # 1-step and 4-step calls
+        h_hip = net.hidden
+        net.clear_hidden_state()
+        net.use_hip_recurrence = False
+        with torch.backends.cudnn.flags(enabled=False):
+            ref = torch.cat([net(x[t:t + 1]) for t in range(9)])
+        h_ref = net.hidden
+    assert rel_err(hip, ref) < 1e-5
+    assert rel_err(h_hip[0], h_ref[0]) < 1e-5 and rel_err(h_hip[1], h_ref[1]) < 1e-5

@@ -45,7 +45,7 @@ def lstm_kernels(B):
         capi.check(lib.kvae_lstm2_forward(T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(),
                                           whh0T.data_ptr(), wih1T.data_ptr(), whh1T.data_ptr(),
                                           b1.data_ptr(), g0.data_ptr(), h0.data_ptr(), c0.data_ptr(),
-                                          g1.data_ptr(), h1.data_ptr(), c1.data_ptr(), st))
+                                          g1.data_ptr(), h1.data_ptr(), c1.data_ptr(), None, None, st))
 
     dx = torch.empty_like(x)
     part = torch.empty(lib.kvae_lstm2_backward_blocks(B), 4 * H * (2 + P), device=dev)
