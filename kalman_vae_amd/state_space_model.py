@@ -322,3 +322,50 @@ class StateSpaceModel(nn.Module):
             symmetrize=symmetrize_covariance, burn_in=burn_in)
         self._finish(as_.device)
         return out
+
+    # -- open-loop rollout (state_space_model.py:486-575) -------------------------
+    def predict_future(self, as_, means, covariances, next_means, next_covariances, mat_As,
+                       mat_Cs, num_steps, sample_control: SampleControl):
+        """Roll the filter ``num_steps`` steps past the end of ``as_`` without
+        observations.  Same returns as the reference: ``(as_tensor, means,
+        covariances, next_means, next_covariances, mat_As_list, mat_Cs_list)`` with
+        lists of per-step tensors.  As in the reference the weight network is fed the
+        whole grown sequence at every step and keeps its cached recurrent state
+        between those calls (:544; it is not cleared), and with "sample" the next
+        covariance is reset to Q (:550-551).  Plain torch ops around the weight
+        network: this is not part of the accelerated path."""
+        T, B = as_.shape[:2]
+        as_list = list(as_)
+        mat_As_list, mat_Cs_list = list(mat_As), list(mat_Cs)
+        means, covariances = list(means), list(covariances)
+        next_means, next_covariances = list(next_means), list(next_covariances)
+        state_noise = wants_noise(sample_control.state_transition, "state_transition")
+        as_tensor = torch.stack(as_list, dim=0)
+        for t_future in range(num_steps):
+            t = T + t_future
+            means.append(next_means[-1])
+            covariances.append(next_covariances[-1])
+            next_z = next_means[-1].reshape(-1, self.z_dim)
+            if state_noise:
+                L = torch.linalg.cholesky(next_covariances[-1])
+                eps = self._draw(next_z.shape, next_z)
+                next_z = next_z + (L @ eps.unsqueeze(-1)).squeeze(-1)
+                next_z = next_z.detach()          # the reference uses .sample(), not .rsample()
+            next_a = (mat_Cs_list[t] * next_z.unsqueeze(-2)).sum(-1)
+            as_list.append(next_a.view(B, self.a_dim))
+            as_tensor = torch.stack(as_list, dim=0)
+            weights = self.weight_model(as_tensor)
+            mat_A = torch.einsum("bk,kij->bij", weights[-1], self.mat_A_K)
+            mat_C = torch.einsum("bk,kij->bij", weights[-1], self.mat_C_K)
+            mat_As_list.append(mat_A)
+            mat_Cs_list.append(mat_C)
+            next_mean = (mat_A * next_means[-1].unsqueeze(-2)).sum(-1)
+            if state_noise:
+                next_covariance = self.mat_Q.unsqueeze(0).repeat(B, 1, 1)
+            else:
+                next_covariance = mat_A @ next_covariances[-1] @ mat_A.transpose(1, 2) + self.mat_Q
+            next_covariance = (next_covariance + next_covariance.transpose(1, 2)) / 2.0
+            next_means.append(next_mean)
+            next_covariances.append(next_covariance)
+        return (as_tensor, means, covariances, next_means, next_covariances, mat_As_list,
+                mat_Cs_list)

@@ -11,6 +11,8 @@ Tolerances (max-norm relative error per tensor): float64 2e-8; float32 1e-4
 against the float64 fixture of the same inputs where one exists (the error of
 the fp32 kernels against the exact answer), 3e-4 against a float32 fixture
 (two independently rounded fp32 computations)."""
+import os
+
 import pytest
 import torch
 
@@ -188,3 +190,35 @@ def test_nonpd_is_reported():
     a = torch.randn(5, 3, 2, device="cuda")
     with pytest.raises(ValueError):
         ssm.kalman_filter(a, SampleControl())
+
+
+@pytest.mark.parametrize("net", ["lstm", "mlp"])
+def test_predict_future_matches_reference(net):
+    """Filter + open-loop rollout (state_space_model.py:486-575) against outputs of
+    the reference itself (tests/golden/make_golden_predict.py), float64, 1e-8."""
+    import numpy as np
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predict",
+                        f"mean_{net}_f64.npz")
+    d = {k: torch.from_numpy(v) for k, v in np.load(path).items()}
+    dev = torch.device("cuda:0")
+    ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network=net, hidden_dim=8,
+                          num_layers=2, init_transition_reg_weight=0.9,
+                          init_observation_reg_weight=0.9)
+    ssm.load_state_dict({k[3:]: v for k, v in d.items() if k.startswith("sd/")})
+    ssm = ssm.double().to(dev).eval()
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition="mean", observation="mean")
+    a = d["as_"].to(dev)
+    with torch.no_grad():
+        m, P, mn, Pn, As, Cs, _, _ = ssm.kalman_filter(a, sample_control=sc)
+        out = ssm.predict_future(a, m, P, mn, Pn, As, Cs, int(d["num_steps"]), sc)
+    for got, key in zip((m, P, mn, Pn, As, Cs), ("filter_means", "filter_covariances",
+                                                  "filter_next_means", "filter_next_covariances",
+                                                  "mat_As", "mat_Cs")):
+        assert rel_err(got.cpu(), d[key]) < 1e-8, key
+    names = ("out_as", "out_means", "out_covariances", "out_next_means", "out_next_covariances",
+             "out_mat_As", "out_mat_Cs")
+    for got, key in zip(out, names):
+        got = got if torch.is_tensor(got) else torch.stack(list(got))
+        assert got.shape == d[key].shape, key
+        assert rel_err(got.cpu(), d[key]) < 1e-8, key
