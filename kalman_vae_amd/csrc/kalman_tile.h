@@ -1,0 +1,459 @@
+// Register-tile variant of the large-state (8 < z_dim <= 32) Kalman filter /
+// RTS smoother / ELBO kernels for gfx950, fp32.
+//
+// Execution model: ONE WAVEFRONT OWNS ONE SEQUENCE and every matrix of the
+// sequence lives in REGISTERS, in the accumulator layout of
+// v_mfma_f32_32x32x2_f32: a (32 x 32) tile is 16 VGPRs, lane l = (j, h) with
+// j = l & 31 and h = l >> 5 holds column j, rows rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h
+// in register r.  Smaller matrices are zero-padded to the tile.
+//
+// The one product the matrix core gives without moving data is
+//     tn(X, Y) = X^T Y
+// (register r of X is the A operand, register r of Y the B operand of the
+// r-th MFMA: both lanes' halves supply rows rho(r, 0) and rho(r, 1), i.e. the
+// contraction runs over the ROW index of both tiles, and the result arrives in
+// the same layout).  Everything is arranged around that:
+//   * symmetric matrices (all covariances) are their own transpose;
+//   * congruences  M^T S M = tn(tn(S, M), M)  need no transpose at all;
+//   * inputs that are needed in both orientations are loaded twice from
+//     global memory (second read hits L2): `load` gives the tile of X,
+//     `load_t` the tile of X^T;
+//   * a tile that was computed here and is needed transposed goes through a
+//     4.2 KB LDS buffer (`transpose`), 32 LDS instructions.
+// Vectors are kept in "lane form" (lane (j, h) holds x_j, both halves the same
+// value); a matrix-vector product  X^T x  reads x_rho through v_readlane
+// ("row form") and adds the two halves.
+// Cholesky factor and triangular inverse run on a row-per-lane copy of the
+// tile (32 registers) with v_readlane broadcasts, as in the LDS variant.
+//
+// No LDS beyond the transpose buffer, so residency is bounded by registers
+// (up to 512 per lane at one wavefront per SIMD), not by the 160 KB LDS: the
+// LDS variant (kalman_wave.h) keeps 60-97 KB of matrices per wavefront and
+// runs one or two wavefronts per CU.
+//
+// Algorithm sources: kvae/state_space_model.py:284-352, :390-477 and
+// kvae/kalman_vae.py:191-242 of the reference; adjoints hand-derived (same
+// equations as kalman_core.h / kalman_wave.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kalman_core.h"
+
+namespace kvae {
+namespace tile {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Tile {
+    f32x16 v;
+};
+// x_{rho(r, h)} for r = 0..15: a vector in the layout of a tile column
+struct Rows {
+    float v[16];
+};
+
+#define KT_DEV __device__ __forceinline__
+#define KT_UNROLL _Pragma("unroll")
+
+constexpr int rho0(int r) { return (r & 3) + 8 * (r >> 2); }  // row of register r, half 0
+
+KT_DEV int lane_col() { return threadIdx.x & 31; }
+KT_DEV int lane_half() { return (threadIdx.x >> 5) & 1; }
+
+// order the wavefront's LDS accesses for the compiler; a single wavefront
+// executes them in program order, so no s_barrier is needed
+KT_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+KT_DEV float bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+KT_DEV float other_half(float v) { return __shfl_xor(v, 32, 64); }
+// sum of a lane-form vector's 32 entries (every lane gets the sum)
+KT_DEV float hsum(float v) {
+    KT_UNROLL
+    for (int m = 16; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+KT_DEV Tile tzero() {
+    Tile t;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) t.v[r] = 0.f;
+    return t;
+}
+
+// C {=, +=, -=} X^T Y, contraction over the first KD rows of both tiles
+template <int KD, int MODE>
+KT_DEV void tn(const Tile& X, const Tile& Y, Tile& C) {
+    static_assert(KD % 8 == 0 && KD <= 32, "rows come in groups of 8");
+    f32x16 acc;
+    if (MODE == 0) {
+        KT_UNROLL
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else {
+        acc = C.v;
+    }
+    KT_UNROLL
+    for (int r = 0; r < KD / 2; ++r)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 2 ? -X.v[r] : X.v[r], Y.v[r], acc, 0, 0, 0);
+    C.v = acc;
+}
+
+// ---- global memory <-> tiles (dense row-major ROWS x COLS matrices) -----------
+// tile of X: v[r] = X[rho][j]
+template <int ROWS, int COLS>
+KT_DEV Tile load(const float* __restrict__ p) {
+    static_assert(ROWS % 8 == 0 && COLS % 8 == 0 && ROWS <= 32 && COLS <= 32, "tile shapes");
+    const int j = lane_col(), h = lane_half();
+    Tile t;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        float val = 0.f;
+        if (rho0(r) < ROWS && (COLS == 32 || j < COLS)) val = p[(rho0(r) + 4 * h) * COLS + j];
+        t.v[r] = val;
+    }
+    return t;
+}
+// tile of X^T: v[r] = X[j][rho]  (lane j reads row j, 16 bytes at a time)
+template <int ROWS, int COLS>
+KT_DEV Tile load_t(const float* __restrict__ p) {
+    static_assert(ROWS % 8 == 0 && COLS % 8 == 0 && ROWS <= 32 && COLS <= 32, "tile shapes");
+    const int j = lane_col(), h = lane_half();
+    Tile t;
+    KT_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (8 * q < COLS && (ROWS == 32 || j < ROWS))
+            val = *reinterpret_cast<const float4*>(p + j * COLS + 8 * q + 4 * h);
+        t.v[4 * q] = val.x;
+        t.v[4 * q + 1] = val.y;
+        t.v[4 * q + 2] = val.z;
+        t.v[4 * q + 3] = val.w;
+    }
+    return t;
+}
+template <int ROWS, int COLS>
+KT_DEV void store(float* __restrict__ p, const Tile& t) {
+    const int j = lane_col(), h = lane_half();
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r)
+        if (rho0(r) < ROWS && (COLS == 32 || j < COLS)) p[(rho0(r) + 4 * h) * COLS + j] = t.v[r];
+}
+// the tile holds X^T; writes X (ROWS x COLS)
+template <int ROWS, int COLS>
+KT_DEV void store_t(float* __restrict__ p, const Tile& t) {
+    const int j = lane_col(), h = lane_half();
+    KT_UNROLL
+    for (int q = 0; q < 4; ++q)
+        if (8 * q < COLS && (ROWS == 32 || j < ROWS))
+            *reinterpret_cast<float4*>(p + j * COLS + 8 * q + 4 * h) =
+                make_float4(t.v[4 * q], t.v[4 * q + 1], t.v[4 * q + 2], t.v[4 * q + 3]);
+}
+
+template <int LEN>
+KT_DEV float vload(const float* __restrict__ p) {
+    const int j = lane_col();
+    return (LEN == 32 || j < LEN) ? p[j] : 0.f;
+}
+template <int LEN>
+KT_DEV void vstore(float* __restrict__ p, float x) {
+    if (threadIdx.x < LEN) p[threadIdx.x] = x;
+}
+
+// ---- vectors --------------------------------------------------------------------
+template <int LEN>
+KT_DEV Rows rows_of(float x) {
+    const int h = lane_half();
+    Rows o;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        if (rho0(r) < LEN) {
+            const float a = bcast(x, rho0(r)), b = bcast(x, rho0(r) + 4);
+            o.v[r] = h ? b : a;
+        } else {
+            o.v[r] = 0.f;
+        }
+    }
+    return o;
+}
+// X^T x over the first KD rows of X (lane form result)
+template <int KD>
+KT_DEV float tv(const Tile& X, const Rows& x) {
+    float acc = 0.f;
+    KT_UNROLL
+    for (int r = 0; r < KD / 2; ++r) acc += X.v[r] * x.v[r];
+    return acc + other_half(acc);
+}
+template <int KD>
+KT_DEV float tv(const Tile& X, float x) {
+    return tv<KD>(X, rows_of<KD>(x));
+}
+// C += s * (u x^T - S) / 2 style updates are written inline by the callers;
+// the plain outer product u x^T:
+KT_DEV Tile outer(float s, const Rows& u, float x) {
+    Tile t;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) t.v[r] = s * u.v[r] * x;
+    return t;
+}
+
+// X^T through LDS (32 x 33 floats)
+KT_DEV Tile transpose(const Tile& X, float* lds) {
+    const int j = lane_col(), h = lane_half();
+    wave_sync();
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) lds[(rho0(r) + 4 * h) * 33 + j] = X.v[r];
+    wave_sync();
+    Tile t;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) t.v[r] = lds[j * 33 + rho0(r) + 4 * h];
+    wave_sync();
+    return t;
+}
+KT_DEV void symmetrize(Tile& X, float* lds) {
+    const Tile t = transpose(X, lds);
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) X.v[r] = (X.v[r] + t.v[r]) * 0.5f;
+}
+
+// ---- Cholesky factor and its inverse -------------------------------------------------
+// S symmetric (N x N in the tile).  Outputs: LT = tile of L^T (v[r] = L[j][rho]),
+// Li = tile of L^-1 (v[r] = Li[rho][j]) when INV, diag = L[j][j] in lane form
+// (1 for j >= N).  Padding stays zero.  Returns false on a pivot <= 0.
+template <int N, bool INV>
+KT_DEV bool chol(const Tile& S, Tile& LT, Tile& Li, float& diag) {
+    static_assert(N % 8 == 0 && N <= 32, "tile shapes");
+    const int i = lane_col(), h = lane_half();
+    float row[N];  // row i of S, then of L
+    KT_UNROLL
+    for (int r = 0; r < N / 2; ++r) {
+        const float mine = S.v[r], theirs = other_half(S.v[r]);
+        row[rho0(r)] = h ? theirs : mine;
+        row[rho0(r) + 4] = h ? mine : theirs;
+    }
+    bool ok = true;
+    diag = 1.f;
+    KT_UNROLL
+    for (int j = 0; j < N; ++j) {
+        float s = row[j];
+        KT_UNROLL
+        for (int k = 0; k < j; ++k) s -= row[k] * bcast(row[k], j);
+        float d = bcast(s, j);
+        if (!(d > 0.f)) {
+            ok = false;
+            d = 1.f;
+        }
+        const float ljj = sqrtf(d);
+        const float inv = 1.f / ljj;
+        row[j] = (i == j) ? ljj : (i > j ? s * inv : 0.f);
+        diag = (i == j) ? ljj : diag;
+    }
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r)
+        LT.v[r] = rho0(r) < N ? (h ? row[(rho0(r) + 4) % N] : row[rho0(r) % N]) : 0.f;
+    if (INV) {
+        const float rdiag = 1.f / diag;
+        float x[N];  // column i of L^-1
+        KT_UNROLL
+        for (int r = 0; r < N; ++r) {
+            float acc = (i == r) ? 1.f : 0.f;
+            KT_UNROLL
+            for (int k = 0; k < r; ++k) acc -= bcast(row[k], r) * x[k];
+            x[r] = acc * bcast(rdiag, r);
+        }
+        KT_UNROLL
+        for (int r = 0; r < 16; ++r)
+            Li.v[r] = rho0(r) < N ? (h ? x[(rho0(r) + 4) % N] : x[rho0(r) % N]) : 0.f;
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// ELBO terms (kvae/kalman_vae.py:191-242), sequential in t per sequence.
+// ---------------------------------------------------------------------------
+
+// Li^T tile of a constant covariance and sum_i log L_ii
+template <int D>
+KT_DEV bool whitener(const float* __restrict__ Sigma, float* lds, Tile& LiT, float& half_logdet) {
+    const Tile S = load<D, D>(Sigma);
+    Tile LT, Li;
+    float dg;
+    const bool ok = chol<D, true>(S, LT, Li, dg);
+    LiT = transpose(Li, lds);
+    half_logdet = hsum(logf(dg));
+    return ok;
+}
+
+template <int N, int P>
+__device__ void elbo_forward_sequence(const ElboFwdArgs<float>& g, int b, float* lds) {
+    const long B = g.B;
+    int st = 0;
+    Tile LiTQ, LiTR, LiT0;
+    float hlQ, hlR, hl0;
+    if (!whitener<N>(g.Q, lds, LiTQ, hlQ)) st |= ST_NONPD_NOISE;
+    if (!whitener<P>(g.Rm, lds, LiTR, hlR)) st |= ST_NONPD_NOISE;
+    if (!whitener<N>(g.P0, lds, LiT0, hl0)) st |= ST_NONPD_NOISE;
+    const float m0 = vload<N>(g.m0);
+    float zp = 0.f;
+    const float c_obs = 0.5f * (float)P * log_2pi<float>(), c_lat = 0.5f * (float)N * log_2pi<float>();
+#pragma unroll 1
+    for (int t = 0; t < g.T; ++t) {
+        const long tb = (long)t * B + b;
+        const Tile S = load<N, N>(g.Ps + tb * N * N);
+        const Tile CT = load_t<P, N>(g.Cs + tb * P * N);
+        const float ms = vload<N>(g.ms + tb * N), e = vload<N>(g.eps + tb * N);
+        const float a = vload<P>(g.a + tb * P);
+        Tile LT, unused;
+        float dg;
+        if (!chol<N, false>(S, LT, unused, dg)) st |= ST_NONPD_SMOOTHED;
+        const float z = ms + tv<N>(LT, e);
+        if (g.z) vstore<N>(g.z + tb * N, z);
+        const float ro = a - tv<N>(CT, z);
+        const float yo = tv<P>(LiTR, ro);
+        const float qo = hsum(yo * yo);
+        float yt, hlt;
+        if (t == 0) {
+            yt = tv<N>(LiT0, z - m0);
+            hlt = hl0;
+        } else {
+            const Tile AT = load_t<N, N>(g.As + tb * N * N);
+            yt = tv<N>(LiTQ, z - tv<N>(AT, zp));
+            hlt = hlQ;
+        }
+        const float qt = hsum(yt * yt), qp = hsum(e * e), hlp = hsum(logf(dg));
+        if (threadIdx.x == 0) {
+            g.obs[tb] = -(c_obs + 0.5f * qo) - hlR;
+            g.trans[tb] = -(c_lat + 0.5f * qt) - hlt;
+            g.post[tb] = -(c_lat + 0.5f * qp) - hlp;
+        }
+        zp = z;
+    }
+    if (st && g.status && threadIdx.x == 0) atomicOr(g.status, st);
+}
+
+// Sigma^-1 tile of a constant covariance
+template <int D>
+KT_DEV Tile precision(const float* __restrict__ Sigma) {
+    const Tile S = load<D, D>(Sigma);
+    Tile LT, Li, Si;
+    float dg;
+    chol<D, true>(S, LT, Li, dg);
+    tn<D, 0>(Li, Li, Si);
+    return Si;
+}
+
+// acc += w/2 (u u^T - Si)
+KT_DEV void cov_grad(float w, const Rows& ur, float u, const Tile& Si, Tile& acc) {
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) acc.v[r] += 0.5f * w * (ur.v[r] * u - Si.v[r]);
+}
+
+template <int N, int P>
+__device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float* lds) {
+    using PG = ElboParamGrads<N, P>;
+    const ElboFwdArgs<float>& f = g.f;
+    const long B = f.B;
+    const int T = f.T;
+    const int j = lane_col(), h = lane_half();
+    const Tile SiQ = precision<N>(f.Q), SiR = precision<P>(f.Rm), Si0 = precision<N>(f.P0);
+    const float m0 = vload<N>(f.m0);
+    Tile dQ = tzero(), dR = tzero(), dP0 = tzero();
+    float dm0 = 0.f;
+    store<N, N>(g.d_As + ((long)T * B + b) * N * N, dQ);
+    store<P, N>(g.d_Cs + ((long)T * B + b) * P * N, dQ);
+    float zn_back = 0.f;  // w_{t+1} A_{t+1}^T u_{t+1}
+    // factor, sample and noise of the pair being processed (cur) and of the
+    // pair before it (prev), which the transition term needs: one factorisation
+    // per iteration, at the top of the loop, for pair t - 1.
+    Tile LT = tzero(), Li = tzero();
+    float z = 0.f, e = 0.f, dg = 1.f;
+#pragma unroll 1
+    for (int t = T; t >= 0; --t) {
+        Tile LTp = tzero(), Lip = tzero();
+        float zp = 0.f, ep = 0.f, dgp = 1.f;
+        if (t > 0) {
+            const long tp = (long)(t - 1) * B + b;
+            const Tile S = load<N, N>(f.Ps + tp * N * N);
+            const float ms = vload<N>(f.ms + tp * N);
+            ep = vload<N>(f.eps + tp * N);
+            chol<N, true>(S, LTp, Lip, dgp);
+            zp = ms + tv<N>(LTp, ep);
+        }
+        if (t < T) {
+            const long tb = (long)t * B + b;
+            const float wo = g.g_obs ? g.g_obs[tb] : 0.f;
+            const float wt = g.g_trans ? g.g_trans[tb] : 0.f;
+            const float wp = g.g_post ? g.g_post[tb] : 0.f;
+            float zb = zn_back;
+            // observation term
+            {
+                const Tile CT = load_t<P, N>(f.Cs + tb * P * N);
+                const Tile C = load<P, N>(f.Cs + tb * P * N);
+                const float ro = vload<P>(f.a + tb * P) - tv<N>(CT, z);
+                const float u = tv<P>(SiR, ro);
+                if (threadIdx.x < P) g.d_a[tb * P + threadIdx.x] = -wo * u;
+                const Rows ur = rows_of<P>(u);
+                store<P, N>(g.d_Cs + tb * P * N, outer(wo, ur, z));
+                zb += wo * tv<P>(C, ur);
+                cov_grad(wo, ur, u, SiR, dR);
+            }
+            // transition term
+            float ut;
+            if (t == 0) {
+                ut = tv<N>(Si0, z - m0);
+                const Rows utr = rows_of<N>(ut);
+                dm0 += wt * ut;
+                cov_grad(wt, utr, ut, Si0, dP0);
+                store<N, N>(g.d_As + tb * N * N, tzero());
+                zn_back = 0.f;
+            } else {
+                const Tile AT = load_t<N, N>(f.As + tb * N * N);
+                const Tile A = load<N, N>(f.As + tb * N * N);
+                ut = tv<N>(SiQ, z - tv<N>(AT, zp));
+                const Rows utr = rows_of<N>(ut);
+                store<N, N>(g.d_As + tb * N * N, outer(wt, utr, zp));
+                cov_grad(wt, utr, ut, SiQ, dQ);
+                zn_back = wt * tv<N>(A, utr);
+            }
+            zb -= wt * ut;
+            vstore<N>(g.d_ms + tb * N, zb);
+            // z = ms + L eps and the posterior term -wp sum log L_ii, through the
+            // factorisation:  d_Ps = L^-T Psi L^-1,  Psi = sym(Phi(L^T tril(Lbar))),
+            // Lbar = zb eps^T - diag(wp / L_ii)  =>  Phi[i][j] = g_i eps_j (i > j),
+            // (g_i eps_i - wp)/2 (i = j) with g = L^T zb.
+            const Tile L = transpose(LT, lds);
+            const float gv = tv<N>(L, zb);
+            const Rows gr = rows_of<N>(gv), er = rows_of<N>(e);
+            Tile Psi;
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row = rho0(r) + 4 * h;
+                const float lo = 0.5f * gr.v[r] * e, up = 0.5f * gv * er.v[r];
+                const float dd = (N == 32 || j < N) ? 0.5f * (gv * e - wp) : 0.f;
+                Psi.v[r] = row > j ? lo : (row < j ? up : dd);
+            }
+            Tile W, dPs;
+            tn<N, 0>(Psi, Li, W);
+            tn<N, 0>(W, Li, dPs);
+            store<N, N>(g.d_Ps + tb * N * N, dPs);
+        }
+        LT = LTp;
+        Li = Lip;
+        z = zp;
+        e = ep;
+        dg = dgp;
+    }
+    (void)dg;
+    float* row = g.partial + (long)b * PG::LEN;
+    store<N, N>(row + PG::OFF_Q, dQ);
+    store<P, P>(row + PG::OFF_R, dR);
+    vstore<N>(row + PG::OFF_M0, dm0);
+    store<N, N>(row + PG::OFF_P0, dP0);
+}
+
+}  // namespace tile
+}  // namespace kvae

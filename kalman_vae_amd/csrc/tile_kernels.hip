@@ -1,0 +1,79 @@
+// Register-tile kernels for large state dimensions (fp32, z_dim and a_dim
+// multiples of 8 up to 32): one wavefront per sequence, all matrices in VGPRs,
+// products on v_mfma_f32_32x32x2_f32 (kalman_tile.h).  The wavefront-per-sequence
+// translation unit (wave_kernels.hip) tries these first and falls back to its
+// LDS-resident kernels for other shapes and for fp64; KVAE_LARGE_STATE=lds in
+// the environment forces the LDS kernels (used by the tests to compare the two).
+#include <cstdlib>
+#include <cstring>
+
+#include "kalman_tile.h"
+#include "launch_common.h"
+#include "wave_api.h"
+
+namespace kvae {
+
+constexpr int TILE_LDS_FLOATS = 32 * 33;
+
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_elbo_forward_kernel(ElboFwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::elbo_forward_sequence<N, P>(g, blockIdx.x, lds);
+}
+
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_elbo_backward_kernel(ElboBwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::elbo_backward_sequence<N, P>(g, blockIdx.x, lds);
+}
+
+// (n, p) compiled for the register-tile path
+#define KVAE_TILE_DIM_LIST(X) \
+    X(32, 16)                 \
+    X(16, 8)
+
+bool tile_enabled() {
+    const char* e = std::getenv("KVAE_LARGE_STATE");
+    return !(e && std::strcmp(e, "lds") == 0);
+}
+
+int tile_supported(int n, int p, int dtype) {
+    if (dtype != KVAE_F32 || !tile_enabled()) return 0;
+#define KVAE_SUP(n_, p_) \
+    if (n == n_ && p == p_) return 1;
+    KVAE_TILE_DIM_LIST(KVAE_SUP)
+#undef KVAE_SUP
+    return 0;
+}
+
+int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
+    ElboFwdArgs<float> g = make_args<float>(d, io);
+#define KVAE_CASE(n_, p_)                                                                       \
+    if (d->n == n_ && d->p == p_) {                                                             \
+        hipLaunchKernelGGL((tile_elbo_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);   \
+        return launch_status();                                                                 \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
+}
+
+int tile_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
+#define KVAE_CASE(n_, p_)                                                                        \
+    if (d->n == n_ && d->p == p_) {                                                              \
+        using PG = ElboParamGrads<n_, p_>;                                                       \
+        if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(float)) return KVAE_E_WORKSPACE;          \
+        ElboBwdArgs<float> g = make_args<float>(d, io, ws);                                      \
+        hipLaunchKernelGGL((tile_elbo_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
+        reduce_elbo_grads<float, n_, p_>(io, ws, d->B, s);                                       \
+        return launch_status();                                                                  \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
+}
+
+}  // namespace kvae

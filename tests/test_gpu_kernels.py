@@ -119,7 +119,27 @@ def test_wave_elbo_f64(be, n, p, K):
     KC.check_elbo(be, T=5, B=3, n=n, p=p, K=K, dtype=torch.float64, seed=n + 1)
 
 
-def test_wave_large_state_f32(be):
+@pytest.fixture(params=["tile", "lds"])
+def large_state(request):
+    """Both large-state fp32 kernel families: matrices in registers (products on
+    the 32x32 matrix-core tile) and matrices in LDS."""
+    os.environ["KVAE_LARGE_STATE"] = request.param
+    yield request.param
+    os.environ.pop("KVAE_LARGE_STATE", None)
+
+
+def test_tile_state16_f32(be, large_state):
+    KC.check_filter(be, T=9, B=4, n=16, p=8, K=4, dtype=torch.float32, seed=41, mask_kind="binary",
+                    burn_in=2)
+    KC.check_smooth(be, T=9, B=4, n=16, p=8, K=4, dtype=torch.float32, seed=42, sample=True,
+                    burn_in=2)
+    KC.check_smooth(be, T=9, B=4, n=16, p=8, K=4, dtype=torch.float32, seed=43, sample=False,
+                    symmetrize=False)
+    KC.check_elbo(be, T=9, B=4, n=16, p=8, K=4, dtype=torch.float32, seed=44)
+    KC.check_elbo(be, T=1, B=3, n=16, p=8, K=4, dtype=torch.float32, seed=45)
+
+
+def test_wave_large_state_f32(be, large_state):
     """BASELINE config 4 shapes (z_dim 32, a_dim 16, K 8) at a test-sized T."""
     KC.check_filter(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=1, mask_kind="binary",
                     burn_in=2)
@@ -129,7 +149,7 @@ def test_wave_large_state_f32(be):
     KC.check_elbo(be, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)
 
 
-def test_wave_long_sequence_drift_f32(be):
+def test_wave_long_sequence_drift_f32(be, large_state):
     """T = 1000 at z_dim 32 in float32 against the float64 oracle: rounding must
     not accumulate over the sequence (outputs and gradients stay within 1e-4)."""
     KC.check_filter(be, T=1000, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=31,
