@@ -455,5 +455,217 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
     store<N, N>(row + PG::OFF_P0, dP0);
 }
 
+
+KT_DEV void tadd(Tile& X, const Tile& Y) {
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) X.v[r] += Y.v[r];
+}
+
+// Adjoint of  z = ms + chol(S) e  w.r.t. S for the cotangent zb of z, plus the
+// adjoint of  -wp sum_i log L_ii:  returns  L^-T Psi L^-1  with
+// Psi = sym(Phi(L^T tril(zb e^T - diag(wp / L_ii)))), i.e. Phi[i][j] = g_i e_j
+// for i > j and (g_i e_i - wp)/2 on the diagonal, g = L^T zb.  LT, Li from chol().
+template <int N, int MODE>
+KT_DEV void chol_sample_adjoint(const Tile& LT, const Tile& Li, float zb, float e, float wp,
+                                float* lds, Tile& out) {
+    const int j = lane_col(), h = lane_half();
+    const Tile L = transpose(LT, lds);
+    const float gv = tv<N>(L, zb);
+    const Rows gr = rows_of<N>(gv), er = rows_of<N>(e);
+    Tile Psi;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int row = rho0(r) + 4 * h;
+        const float lo = 0.5f * gr.v[r] * e, up = 0.5f * gv * er.v[r];
+        const float dd = (N == 32 || j < N) ? 0.5f * (gv * e - wp) : 0.f;
+        Psi.v[r] = row > j ? lo : (row < j ? up : dd);
+    }
+    Tile W;
+    tn<N, 0>(Psi, Li, W);
+    tn<N, MODE>(W, Li, out);
+}
+
+// ---------------------------------------------------------------------------
+// RTS smoother (kvae/state_space_model.py:390-477), t = T-1 .. 0.
+// With J = Pf An^T Pn^-1:  W = An^T Pn^-1 = tn(An, Pi),  J^T = W^T Pf = tn(W, Pf),
+// J d = tv(J^T, d),  J D J^T = tn(tn(D, J^T), J^T).
+// ---------------------------------------------------------------------------
+template <int N, int P>
+__device__ void smooth_forward_sequence(const SmoothFwdArgs<float>& g, int b, float* lds) {
+    const long B = g.B;
+    const int T = g.T;
+    int st = 0;
+    Tile LRT = tzero();
+    if (g.eps_o) LRT = load_t<P, P>(g.LR);
+    float ms = 0.f;
+    Tile Ps = tzero();
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+        const long tb = (long)t * B + b;
+        const bool last = t == T - 1;
+        const Tile Pf = load<N, N>(g.Pf + tb * N * N);
+        const float m = vload<N>(g.m + tb * N);
+        const Tile CT = load_t<P, N>(g.Cs + (last ? tb + B : tb) * P * N);
+        if (last) {
+            ms = m;
+            Ps = Pf;
+        } else {
+            const Tile Pn = load<N, N>(g.Pn + tb * N * N);
+            const Tile An = load<N, N>(g.As + (tb + B) * N * N);
+            const float mn = vload<N>(g.mn + tb * N);
+            Tile LT, Li, Pi, W, JT, X;
+            float dg;
+            if (!chol<N, true>(Pn, LT, Li, dg)) st |= ST_NONPD_PREDICTED;
+            tn<N, 0>(Li, Li, Pi);
+            tn<N, 0>(An, Pi, W);
+            tn<N, 0>(W, Pf, JT);
+            ms = m + tv<N>(JT, ms - mn);
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) Ps.v[r] -= Pn.v[r];
+            tn<N, 0>(Ps, JT, X);
+            Ps = Pf;
+            tn<N, 1>(X, JT, Ps);
+            if (g.symmetrize) symmetrize(Ps, lds);
+        }
+        vstore<N>(g.ms + tb * N, ms);
+        store<N, N>(g.Ps + tb * N * N, Ps);
+        float z = ms;
+        if (g.eps_s) {
+            Tile LT, unused;
+            float dg;
+            if (!chol<N, false>(Ps, LT, unused, dg)) st |= ST_NONPD_SMOOTHED;
+            z += tv<N>(LT, vload<N>(g.eps_s + tb * N));
+        }
+        float ar = tv<N>(CT, z);
+        if (g.eps_o) ar += tv<P>(LRT, vload<P>(g.eps_o + tb * P));
+        vstore<N>(g.zs + tb * N, z);
+        vstore<P>(g.ares + tb * P, ar);
+    }
+    if (st && g.status && threadIdx.x == 0) atomicOr(g.status, st);
+}
+
+// Adjoint, t = 0 .. T-1, carrying (msb, G) = cotangents of (ms_t, Ps_t).
+template <int N, int P>
+__device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, float* lds) {
+    const SmoothFwdArgs<float>& f = g.f;
+    const long B = f.B;
+    const int T = f.T;
+    const bool emit = g.g_ares || g.g_zs;
+    Tile dLR = tzero();
+    {
+        const Tile zero = tzero();
+        store<N, N>(g.d_As + (long)b * N * N, zero);
+        store<N, N>(g.d_As + ((long)T * B + b) * N * N, zero);
+        store<P, N>(g.d_Cs + ((long)(T - 1) * B + b) * P * N, zero);
+        vstore<N>(g.d_mn + ((long)(T - 1) * B + b) * N, 0.f);
+        store<N, N>(g.d_Pn + ((long)(T - 1) * B + b) * N * N, zero);
+    }
+    float msb = 0.f;
+    Tile G = tzero();
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const long tb = (long)t * B + b;
+        const bool last = t == T - 1;
+        const float ms = vload<N>(f.ms + tb * N);
+        const Tile Ps = load<N, N>(f.Ps + tb * N * N);
+        if (g.g_ms) msb += vload<N>(g.g_ms + tb * N);
+        if (g.g_Ps) tadd(G, load<N, N>(g.g_Ps + tb * N * N));
+        // emission adjoint: zs = ms + chol(Ps) eps_s, ares = C zs + LR eps_o
+        float* dC = g.d_Cs + (last ? tb + B : tb) * P * N;
+        if (emit) {
+            const float* Cp = f.Cs + (last ? tb + B : tb) * P * N;
+            float zb = g.g_zs ? vload<N>(g.g_zs + tb * N) : 0.f;
+            Tile LT = tzero(), Li = tzero();
+            float dg, e = 0.f;
+            if (f.eps_s) {
+                chol<N, true>(Ps, LT, Li, dg);
+                e = vload<N>(f.eps_s + tb * N);
+            }
+            if (g.g_ares) {
+                const float ab = vload<P>(g.g_ares + tb * P);
+                const float z = ms + tv<N>(LT, e);
+                const Rows abr = rows_of<P>(ab);
+                store<P, N>(dC, outer(1.f, abr, z));
+                zb += tv<P>(load<P, N>(Cp), abr);
+                if (f.eps_o && g.partial) {
+                    const float eo = vload<P>(f.eps_o + tb * P);
+                    KT_UNROLL
+                    for (int r = 0; r < 16; ++r) dLR.v[r] += abr.v[r] * eo;
+                }
+            } else {
+                store<P, N>(dC, tzero());
+            }
+            msb += zb;
+            if (f.eps_s) chol_sample_adjoint<N, 1>(LT, Li, zb, e, 0.f, lds, G);
+        } else {
+            store<P, N>(dC, tzero());
+        }
+        if (last) {
+            vstore<N>(g.d_m + tb * N, msb);
+            store<N, N>(g.d_P + tb * N * N, G);
+        } else {
+            if (t < g.burn_in) {
+                msb = 0.f;
+                G = tzero();
+            }
+            const Tile Pf = load<N, N>(f.Pf + tb * N * N);
+            const Tile Pn = load<N, N>(f.Pn + tb * N * N);
+            const Tile An = load<N, N>(f.As + (tb + B) * N * N);
+            const Tile AnT = load_t<N, N>(f.As + (tb + B) * N * N);
+            Tile D = load<N, N>(f.Ps + (tb + B) * N * N);
+            const float d = vload<N>(f.ms + (tb + B) * N) - vload<N>(f.mn + tb * N);
+            Tile LT, Li, Pi, W, WT, J;
+            float dg;
+            chol<N, true>(Pn, LT, Li, dg);
+            tn<N, 0>(Li, Li, Pi);
+            tn<N, 0>(An, Pi, W);
+            tn<N, 0>(Pi, An, WT);
+            tn<N, 0>(Pf, W, J);
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) D.v[r] -= Pn.v[r];
+            // Gsum = G + G^T (and G made symmetric when the forward pass did so)
+            Tile Gsum = transpose(G, lds);
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) Gsum.v[r] += G.v[r];
+            if (f.symmetrize) {
+                KT_UNROLL
+                for (int r = 0; r < 16; ++r) G.v[r] = 0.5f * Gsum.v[r];
+            }
+            vstore<N>(g.d_m + tb * N, msb);
+            // Jb = msb d^T + (G + G^T) J D and its transpose
+            Tile MT, Jb, JbT;
+            tn<N, 0>(J, Gsum, MT);
+            const Rows msbr = rows_of<N>(msb), dr = rows_of<N>(d);
+            Jb = outer(1.f, msbr, d);
+            tn<N, 1>(MT, D, Jb);
+            JbT = outer(1.f, dr, msb);
+            tn<N, 1>(D, MT, JbT);
+            const float db = tv<N>(J, msb);
+            Tile X1, Db;
+            tn<N, 0>(G, J, X1);
+            tn<N, 0>(X1, J, Db);
+            // Pfb = G + Jb W^T
+            tn<N, 1>(JbT, WT, G);
+            store<N, N>(g.d_P + tb * N * N, G);
+            Tile Wb, WbT, Anb, PibT, Z;
+            tn<N, 0>(Pf, Jb, Wb);
+            tn<N, 0>(Jb, Pf, WbT);
+            tn<N, 0>(Pi, WbT, Anb);
+            store<N, N>(g.d_As + (tb + B) * N * N, Anb);
+            tn<N, 0>(Wb, AnT, PibT);
+            tn<N, 0>(PibT, Pi, Z);
+            Tile Pnb;
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) Pnb.v[r] = -Db.v[r];
+            tn<N, 2>(Pi, Z, Pnb);
+            store<N, N>(g.d_Pn + tb * N * N, Pnb);
+            vstore<N>(g.d_mn + tb * N, -db);
+            msb = db;
+            G = Db;
+        }
+    }
+    if (g.partial) store<P, P>(g.partial + (long)b * (P * P), dLR);
+}
+
 }  // namespace tile
 }  // namespace kvae

@@ -27,6 +27,18 @@ __global__ void __launch_bounds__(64) tile_elbo_backward_kernel(ElboBwdArgs<floa
     tile::elbo_backward_sequence<N, P>(g, blockIdx.x, lds);
 }
 
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_smooth_forward_kernel(SmoothFwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::smooth_forward_sequence<N, P>(g, blockIdx.x, lds);
+}
+
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_smooth_backward_kernel(SmoothBwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::smooth_backward_sequence<N, P>(g, blockIdx.x, lds);
+}
+
 // (n, p) compiled for the register-tile path
 #define KVAE_TILE_DIM_LIST(X) \
     X(32, 16)                 \
@@ -44,6 +56,35 @@ int tile_supported(int n, int p, int dtype) {
     KVAE_TILE_DIM_LIST(KVAE_SUP)
 #undef KVAE_SUP
     return 0;
+}
+
+int tile_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
+    SmoothFwdArgs<float> g = make_args<float>(d, io);
+#define KVAE_CASE(n_, p_)                                                                        \
+    if (d->n == n_ && d->p == p_) {                                                              \
+        hipLaunchKernelGGL((tile_smooth_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
+        return launch_status();                                                                  \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
+}
+
+int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
+#define KVAE_CASE(n_, p_)                                                                         \
+    if (d->n == n_ && d->p == p_) {                                                               \
+        if (io->d_LR && ws_bytes < (size_t)d->B * p_ * p_ * sizeof(float)) return KVAE_E_WORKSPACE; \
+        SmoothBwdArgs<float> g = make_args<float>(d, io, ws);                                     \
+        hipLaunchKernelGGL((tile_smooth_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
+        if (io->d_LR) reduce_smooth_grads<float, p_>(io, ws, d->B, s);                            \
+        return launch_status();                                                                   \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
 }
 
 int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {

@@ -300,6 +300,7 @@ int wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws
     return KVAE_E_UNSUPPORTED;
 }
 int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
+    if (tile_supported(d->n, d->p, d->dtype)) return tile_smooth_forward(d, io, s);
 #define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_forward<R, n_, p_>(d, io, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
@@ -307,6 +308,7 @@ int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream
 }
 int wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
                          hipStream_t s) {
+    if (tile_supported(d->n, d->p, d->dtype)) return tile_smooth_backward(d, io, ws, ws_bytes, s);
 #define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_backward<R, n_, p_>(d, io, ws, ws_bytes, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
