@@ -667,5 +667,231 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
     if (g.partial) store<P, P>(g.partial + (long)b * (P * P), dLR);
 }
 
+
+// ---------------------------------------------------------------------------
+// Filter (kvae/state_space_model.py:284-352).
+// With CT = tile of C^T and Pp symmetric:  F = Pp C^T = tn(Pp, CT),
+// M = C Pp = tn(CT, Pp) = F^T,  S = R + C Pp C^T = R + tn(F, CT),
+// G r = F Si r = tv(M, tv(Si, r)),  G M = M^T Si M = tn(tn(Si, M), M),
+// An Pf An^T = tn(tn(Pf, AnT), AnT) with AnT = tile of An^T.
+// ---------------------------------------------------------------------------
+
+// tile of (sum_k w[k] X_k)^T for K dense row-major (ROWS x COLS) bases; w is
+// wave-uniform (scalar loads), lane j reads row j of every basis.
+template <int ROWS, int COLS>
+KT_DEV Tile mix_t(int K, const float* __restrict__ w, const float* __restrict__ bases) {
+    const int j = lane_col(), h = lane_half();
+    Tile t = tzero();
+    if (ROWS == 32 || j < ROWS) {
+#pragma unroll 2
+        for (int k = 0; k < K; ++k) {
+            const float wk = w[k];
+            const float* p = bases + (long)k * ROWS * COLS + j * COLS + 4 * h;
+            KT_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                if (8 * q < COLS) {
+                    const float4 val = *reinterpret_cast<const float4*>(p + 8 * q);
+                    t.v[4 * q] += wk * val.x;
+                    t.v[4 * q + 1] += wk * val.y;
+                    t.v[4 * q + 2] += wk * val.z;
+                    t.v[4 * q + 3] += wk * val.w;
+                }
+            }
+        }
+    }
+    return t;
+}
+
+// F, M, S^-1 and the innovation of one measurement update
+template <int N, int P>
+KT_DEV bool update_terms(const Tile& Pp, const Tile& CT, const Tile& Rm, float a, float mp, Tile& F,
+                         Tile& M, Tile& Si, float& r) {
+    tn<N, 0>(Pp, CT, F);
+    tn<N, 0>(CT, Pp, M);
+    Tile S = Rm;
+    tn<N, 1>(F, CT, S);
+    Tile LT, Li;
+    float dg;
+    const bool ok = chol<P, true>(S, LT, Li, dg);
+    tn<P, 0>(Li, Li, Si);
+    r = a - tv<N>(CT, mp);
+    return ok;
+}
+
+template <int N, int P>
+__device__ void filter_forward_sequence(const FilterFwdArgs<float>& g, int K, int b, float* lds) {
+    const long B = g.B;
+    const Tile Rm = load<P, P>(g.Rm), Q = load<N, N>(g.Q);
+    float mp = vload<N>(g.m_in + (g.carry_per_sequence ? (long)b * N : 0));
+    Tile Pp = load<N, N>(g.P_in + (g.carry_per_sequence ? (long)b * N * N : 0));
+    if (g.As) store_t<N, N>(g.As + (long)b * N * N, mix_t<N, N>(K, g.alpha + (long)b * K, g.A_K));
+    int st = 0;
+#pragma unroll 1
+    for (int t = 0; t < g.T; ++t) {
+        const long tb = (long)t * B + b;
+        const Tile CT = mix_t<P, N>(K, g.alpha + tb * K, g.C_K);
+        const Tile AnT = mix_t<N, N>(K, g.alpha + (tb + B) * K, g.A_K);
+        if (g.Cs) store_t<P, N>(g.Cs + tb * P * N, CT);
+        if (g.As) store_t<N, N>(g.As + (tb + B) * N * N, AnT);
+        const float a = vload<P>(g.a + tb * P);
+        const float mu = g.mask ? g.mask[tb] : 1.f;
+        Tile F, M, Si, X;
+        float r;
+        if (!update_terms<N, P>(Pp, CT, Rm, a, mp, F, M, Si, r)) st |= ST_NONPD_INNOVATION;
+        const float m = mp + mu * tv<P>(M, tv<P>(Si, r));
+        tn<P, 0>(Si, M, X);
+        Tile Y;
+        tn<P, 0>(X, M, Y);
+        Tile Pf;
+        KT_UNROLL
+        for (int q = 0; q < 16; ++q) Pf.v[q] = Pp.v[q] - mu * Y.v[q];
+        if (g.symmetrize) symmetrize(Pf, lds);
+        mp = tv<N>(AnT, m);
+        tn<N, 0>(Pf, AnT, X);
+        Pp = Q;
+        tn<N, 1>(X, AnT, Pp);
+        if (g.symmetrize) symmetrize(Pp, lds);
+        vstore<N>(g.m + tb * N, m);
+        store<N, N>(g.Pf + tb * N * N, Pf);
+        vstore<N>(g.mn + tb * N, mp);
+        store<N, N>(g.Pn + tb * N * N, Pp);
+    }
+    if (g.Cs)
+        store_t<P, N>(g.Cs + ((long)g.T * B + b) * P * N,
+                      mix_t<P, N>(K, g.alpha + ((long)g.T * B + b) * K, g.C_K));
+    if (st && g.status && threadIdx.x == 0) atomicOr(g.status, st);
+}
+
+template <int ROWS, int COLS>
+KT_DEV Tile load_or_zero(const float* __restrict__ base, long off) {
+    return base ? load<ROWS, COLS>(base + off) : tzero();
+}
+
+// Adjoint, t = T-1 .. 0, carrying (mpb, Ppb) = cotangents of the predicted
+// (mean, covariance) entering step t.  Needs the forward pass's stored mixed
+// matrices (f.As, f.Cs); writes the gradients w.r.t. them (bar_As, bar_Cs) for
+// the separate mixing-adjoint pass, and one row [dQ | dR] of partial sums.
+template <int N, int P>
+__device__ void filter_backward_sequence(const FilterBwdArgs<float>& g, int b, float* lds) {
+    const FilterFwdArgs<float>& f = g.f;
+    const long B = f.B;
+    const int T = f.T;
+    const Tile Rm = load<P, P>(f.Rm);
+    Tile dQ = tzero(), dR = tzero();
+    store<P, N>(g.bar_Cs + ((long)T * B + b) * P * N,
+                load_or_zero<P, N>(g.g_Cs, ((long)T * B + b) * P * N));
+    float mpb = 0.f;
+    Tile Ppb = tzero();
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+        const long tb = (long)t * B + b;
+        const Tile C = load<P, N>(f.Cs + tb * P * N), CT = load_t<P, N>(f.Cs + tb * P * N);
+        const Tile An = load<N, N>(f.As + (tb + B) * N * N);
+        const float a = vload<P>(f.a + tb * P);
+        float mp;
+        Tile Pp;
+        if (t > 0) {
+            mp = vload<N>(f.mn + (tb - B) * N);
+            Pp = load<N, N>(f.Pn + (tb - B) * N * N);
+        } else {
+            mp = vload<N>(f.m_in + (f.carry_per_sequence ? (long)b * N : 0));
+            Pp = load<N, N>(f.P_in + (f.carry_per_sequence ? (long)b * N * N : 0));
+        }
+        const float m = vload<N>(f.m + tb * N);
+        const Tile Pf = load<N, N>(f.Pf + tb * N * N);
+        float mb = g.g_m ? vload<N>(g.g_m + tb * N) : 0.f;
+        Tile Pb = load_or_zero<N, N>(g.g_P, tb * N * N);
+        if (g.g_mn) mpb += vload<N>(g.g_mn + tb * N);
+        if (g.g_Pn) tadd(Ppb, load<N, N>(g.g_Pn + tb * N * N));
+        if (t < g.burn_in) {
+            mb = 0.f;
+            mpb = 0.f;
+            Pb = tzero();
+            Ppb = tzero();
+        }
+        // time update adjoint:  mn = An m,  Pn = An Pf An^T + Q
+        {
+            Tile Hs = transpose(Ppb, lds);  // Ppb + Ppb^T
+            KT_UNROLL
+            for (int r = 0; r < 16; ++r) Hs.v[r] += Ppb.v[r];
+            if (f.symmetrize) {
+                KT_UNROLL
+                for (int r = 0; r < 16; ++r) Ppb.v[r] = 0.5f * Hs.v[r];
+            }
+            Tile Ab = load_or_zero<N, N>(g.g_As, (tb + B) * N * N);
+            tadd(Ab, outer(1.f, rows_of<N>(mpb), m));
+            Tile X;
+            tn<N, 0>(An, Hs, X);
+            tn<N, 1>(X, Pf, Ab);
+            store<N, N>(g.bar_As + (tb + B) * N * N, Ab);
+            mb += tv<N>(An, mpb);
+            tn<N, 0>(Ppb, An, X);
+            tn<N, 1>(X, An, Pb);
+            tadd(dQ, Ppb);
+        }
+        // measurement update adjoint
+        Tile F, M, Si, G;
+        float r;
+        update_terms<N, P>(Pp, CT, Rm, a, mp, F, M, Si, r);
+        tn<P, 0>(M, Si, G);
+        const float mu = f.mask ? f.mask[tb] : 1.f;
+        Tile PbT = transpose(Pb, lds);
+        if (f.symmetrize) {
+            KT_UNROLL
+            for (int q = 0; q < 16; ++q) {
+                Pb.v[q] = 0.5f * (Pb.v[q] + PbT.v[q]);
+                PbT.v[q] = Pb.v[q];
+            }
+        }
+        Tile Cb = load_or_zero<P, N>(g.g_Cs, tb * P * N);
+        const float mob = mu * mb;
+        mpb = mb;
+        Ppb = Pb;
+        Tile Pob, PobT;
+        KT_UNROLL
+        for (int q = 0; q < 16; ++q) {
+            Pob.v[q] = mu * Pb.v[q];
+            PobT.v[q] = mu * PbT.v[q];
+        }
+        const Rows mobr = rows_of<N>(mob), rr = rows_of<P>(r);
+        Tile Gb = outer(1.f, mobr, r), GbT = outer(1.f, rr, mob);
+        tn<N, 2>(PobT, F, Gb);
+        tn<N, 2>(F, PobT, GbT);
+        const float rb = tv<N>(G, mob);
+        vstore<P>(g.d_a + tb * P, rb);
+        const Rows rbr = rows_of<P>(rb);
+        KT_UNROLL
+        for (int q = 0; q < 16; ++q) Cb.v[q] -= rbr.v[q] * mp;
+        mpb -= tv<P>(C, rbr);
+        Tile Mb, MbT;
+        tn<N, 0>(G, Pob, Mb);
+        tn<N, 0>(Pob, G, MbT);
+        tn<N, 2>(MbT, Pp, Cb);
+        tn<P, 2>(C, Mb, Ppb);
+        Tile Fb, FbT, Sib, U, Sb;
+        tn<P, 0>(GbT, Si, Fb);
+        tn<P, 0>(Si, GbT, FbT);
+        tn<N, 0>(F, Gb, Sib);
+        tn<P, 0>(Sib, Si, U);
+        Sb = tzero();
+        tn<P, 2>(U, Si, Sb);
+        tn<P, 1>(FbT, C, Ppb);
+        tn<N, 1>(Fb, Pp, Cb);
+        Tile Ssum = transpose(Sb, lds);
+        tadd(Ssum, Sb);
+        tn<P, 1>(Ssum, M, Cb);
+        tn<P, 0>(Sb, C, U);
+        tn<P, 1>(U, C, Ppb);
+        tadd(dR, Sb);
+        store<P, N>(g.bar_Cs + tb * P * N, Cb);
+    }
+    store<N, N>(g.bar_As + (long)b * N * N, load_or_zero<N, N>(g.g_As, (long)b * N * N));
+    vstore<N>(g.d_m_in + (long)b * N, mpb);
+    store<N, N>(g.d_P_in + (long)b * N * N, Ppb);
+    float* row = g.partial + (long)b * (N * N + P * P);
+    store<N, N>(row, dQ);
+    store<P, P>(row + N * N, dR);
+}
+
 }  // namespace tile
 }  // namespace kvae

@@ -39,6 +39,18 @@ __global__ void __launch_bounds__(64) tile_smooth_backward_kernel(SmoothBwdArgs<
     tile::smooth_backward_sequence<N, P>(g, blockIdx.x, lds);
 }
 
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_filter_forward_kernel(FilterFwdArgs<float> g, int K) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::filter_forward_sequence<N, P>(g, K, blockIdx.x, lds);
+}
+
+template <int N, int P>
+__global__ void __launch_bounds__(64) tile_filter_backward_kernel(FilterBwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS];
+    tile::filter_backward_sequence<N, P>(g, blockIdx.x, lds);
+}
+
 // (n, p) compiled for the register-tile path
 #define KVAE_TILE_DIM_LIST(X) \
     X(32, 16)                 \
@@ -56,6 +68,34 @@ int tile_supported(int n, int p, int dtype) {
     KVAE_TILE_DIM_LIST(KVAE_SUP)
 #undef KVAE_SUP
     return 0;
+}
+
+int tile_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
+    FilterFwdArgs<float> g = make_args<float>(d, io);
+#define KVAE_CASE(n_, p_)                                                                        \
+    if (d->n == n_ && d->p == p_) {                                                              \
+        hipLaunchKernelGGL((tile_filter_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g,   \
+                           d->K);                                                                \
+        return launch_status();                                                                  \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
+}
+
+// the per-sequence recursion of the filter backward only; the caller runs the
+// reductions and the mixing-adjoint passes over bar_As / bar_Cs
+int tile_filter_backward_main(const kvae_dims* d, const FilterBwdArgs<float>& g, hipStream_t s) {
+    if (!tile_supported(d->n, d->p, d->dtype) || !g.f.As || !g.f.Cs) return KVAE_E_UNSUPPORTED;
+#define KVAE_CASE(n_, p_)                                                                        \
+    if (d->n == n_ && d->p == p_) {                                                              \
+        hipLaunchKernelGGL((tile_filter_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g); \
+        return KVAE_OK;                                                                          \
+    }
+    KVAE_TILE_DIM_LIST(KVAE_CASE)
+#undef KVAE_CASE
+    return KVAE_E_UNSUPPORTED;
 }
 
 int tile_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {

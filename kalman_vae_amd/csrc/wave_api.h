@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/kvae_kalman.h"
+#include "kalman_core.h"
 
 namespace kvae {
 int wave_supported(int n, int p, int K, int dtype);
@@ -25,6 +26,8 @@ int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, si
 // Register-tile kernels (tile_kernels.hip): fp32, n and p multiples of 8 up to 32.
 // KVAE_E_UNSUPPORTED means "use the LDS kernels".
 int tile_supported(int n, int p, int dtype);
+int tile_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s);
+int tile_filter_backward_main(const kvae_dims* d, const FilterBwdArgs<float>& g, hipStream_t s);
 int tile_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s);
 int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
                          hipStream_t s);

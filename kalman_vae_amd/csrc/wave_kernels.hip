@@ -165,7 +165,11 @@ int run_wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void
         FilterBwdArgs<R> g = make_args<R>(d, io, qr_partial);
         g.bar_As = bar_As;
         g.bar_Cs = bar_Cs;
-        hipLaunchKernelGGL((wave_filter_backward_kernel<R, N, P, K>), dim3(d->B), dim3(64), 0, s, g);
+        bool launched = false;
+        if constexpr (sizeof(R) == 4) launched = tile_filter_backward_main(d, g, s) == KVAE_OK;
+        if (!launched)
+            hipLaunchKernelGGL((wave_filter_backward_kernel<R, N, P, K>), dim3(d->B), dim3(64), 0, s,
+                               g);
         {   // d_Q, d_R: sum the per-sequence rows
             void* outs[2] = {io->d_Q, io->d_R};
             const int begin[3] = {0, N * N, QR};
@@ -287,6 +291,7 @@ size_t wave_workspace_bytes(const kvae_dims* d, int op) {
 }
 
 int wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
+    if (tile_supported(d->n, d->p, d->dtype)) return tile_filter_forward(d, io, s);
 #define KVAE_CALL(R, n_, p_, K_) run_wave_filter_forward<R, n_, p_, K_>(d, io, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
