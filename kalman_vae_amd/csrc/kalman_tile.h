@@ -235,32 +235,42 @@ KT_DEV bool chol(const Tile& S, Tile& LT, Tile& Li, float& diag) {
         row[rho0(r)] = h ? theirs : mine;
         row[rho0(r) + 4] = h ? mine : theirs;
     }
-    bool ok = true;
+    float dmin = 1.f;  // smallest pivot seen (factorisation fails when <= 0)
     diag = 1.f;
+    float rdiag = 1.f;
     KT_UNROLL
     for (int j = 0; j < N; ++j) {
         float s = row[j];
         KT_UNROLL
         for (int k = 0; k < j; ++k) s -= row[k] * bcast(row[k], j);
         float d = bcast(s, j);
-        if (!(d > 0.f)) {
-            ok = false;
-            d = 1.f;
-        }
-        const float ljj = sqrtf(d);
-        const float inv = 1.f / ljj;
-        row[j] = (i == j) ? ljj : (i > j ? s * inv : 0.f);
-        diag = (i == j) ? ljj : diag;
+        dmin = fminf(dmin, d);
+        d = d > 0.f ? d : 1.f;
+        const float inv = __builtin_amdgcn_rsqf(d);  // 1 ulp
+        const float ljj = d * inv;
+        // the lane comparisons are recomputed per column: hoisted out of the
+        // caller's loop over t they would occupy 128 scalar registers
+        int ii = i;
+        asm volatile("" : "+v"(ii));
+        row[j] = (ii == j) ? ljj : (ii > j ? s * inv : 0.f);
+        diag = (ii == j) ? ljj : diag;
+        rdiag = (ii == j) ? inv : rdiag;
     }
+    const bool ok = dmin > 0.f;
     KT_UNROLL
     for (int r = 0; r < 16; ++r)
         LT.v[r] = rho0(r) < N ? (h ? row[(rho0(r) + 4) % N] : row[rho0(r) % N]) : 0.f;
     if (INV) {
-        const float rdiag = 1.f / diag;
+        // the broadcasts of L below repeat those of the factorisation; keeping
+        // all of them alive in scalar registers would spill, so hide the reuse
+        KT_UNROLL
+        for (int k = 0; k < N; ++k) asm volatile("" : "+v"(row[k]));
         float x[N];  // column i of L^-1
         KT_UNROLL
         for (int r = 0; r < N; ++r) {
-            float acc = (i == r) ? 1.f : 0.f;
+            int ii = i;
+            asm volatile("" : "+v"(ii));
+            float acc = (ii == r) ? 1.f : 0.f;
             KT_UNROLL
             for (int k = 0; k < r; ++k) acc -= bcast(row[k], r) * x[k];
             x[r] = acc * bcast(rdiag, r);
