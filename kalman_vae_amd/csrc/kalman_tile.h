@@ -227,22 +227,31 @@ KT_DEV void symmetrize(Tile& X, float* lds) {
 template <int N, bool INV>
 KT_DEV bool chol(const Tile& S, Tile& LT, Tile& Li, float& diag) {
     static_assert(N % 8 == 0 && N <= 32, "tile shapes");
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const int i = lane_col(), h = lane_half();
-    float row[N];  // row i of S, then of L
+    // row i of S, then of L, as register pairs: the dot products below run on
+    // v_pk_fma_f32 with a pair of broadcast values as the scalar operand
+    f2 row[N / 2];
     KT_UNROLL
     for (int r = 0; r < N / 2; ++r) {
         const float mine = S.v[r], theirs = other_half(S.v[r]);
-        row[rho0(r)] = h ? theirs : mine;
-        row[rho0(r) + 4] = h ? mine : theirs;
+        const int c0 = rho0(r), c1 = rho0(r) + 4;
+        row[c0 / 2][c0 % 2] = h ? theirs : mine;
+        row[c1 / 2][c1 % 2] = h ? mine : theirs;
     }
     float dmin = 1.f;  // smallest pivot seen (factorisation fails when <= 0)
     diag = 1.f;
     float rdiag = 1.f;
     KT_UNROLL
     for (int j = 0; j < N; ++j) {
-        float s = row[j];
+        f2 acc = {0.f, 0.f};
         KT_UNROLL
-        for (int k = 0; k < j; ++k) s -= row[k] * bcast(row[k], j);
+        for (int q = 0; q < j / 2; ++q) {
+            const f2 lj = {bcast(row[q][0], j), bcast(row[q][1], j)};
+            acc += row[q] * lj;
+        }
+        float s = row[j / 2][j % 2] - (acc[0] + acc[1]);
+        if (j % 2) s -= row[j / 2][0] * bcast(row[j / 2][0], j);
         float d = bcast(s, j);
         dmin = fminf(dmin, d);
         d = d > 0.f ? d : 1.f;
@@ -252,32 +261,41 @@ KT_DEV bool chol(const Tile& S, Tile& LT, Tile& Li, float& diag) {
         // caller's loop over t they would occupy 128 scalar registers
         int ii = i;
         asm volatile("" : "+v"(ii));
-        row[j] = (ii == j) ? ljj : (ii > j ? s * inv : 0.f);
+        row[j / 2][j % 2] = (ii == j) ? ljj : (ii > j ? s * inv : 0.f);
         diag = (ii == j) ? ljj : diag;
         rdiag = (ii == j) ? inv : rdiag;
     }
     const bool ok = dmin > 0.f;
     KT_UNROLL
-    for (int r = 0; r < 16; ++r)
-        LT.v[r] = rho0(r) < N ? (h ? row[(rho0(r) + 4) % N] : row[rho0(r) % N]) : 0.f;
+    for (int r = 0; r < 16; ++r) {
+        const int c0 = rho0(r) % N, c1 = (rho0(r) + 4) % N;
+        LT.v[r] = rho0(r) < N ? (h ? row[c1 / 2][c1 % 2] : row[c0 / 2][c0 % 2]) : 0.f;
+    }
     if (INV) {
         // the broadcasts of L below repeat those of the factorisation; keeping
         // all of them alive in scalar registers would spill, so hide the reuse
         KT_UNROLL
-        for (int k = 0; k < N; ++k) asm volatile("" : "+v"(row[k]));
-        float x[N];  // column i of L^-1
+        for (int k = 0; k < N / 2; ++k) asm volatile("" : "+v"(row[k]));
+        f2 x[N / 2];  // column i of L^-1
         KT_UNROLL
         for (int r = 0; r < N; ++r) {
             int ii = i;
             asm volatile("" : "+v"(ii));
-            float acc = (ii == r) ? 1.f : 0.f;
+            f2 acc = {0.f, 0.f};
             KT_UNROLL
-            for (int k = 0; k < r; ++k) acc -= bcast(row[k], r) * x[k];
-            x[r] = acc * bcast(rdiag, r);
+            for (int q = 0; q < r / 2; ++q) {
+                const f2 lr = {bcast(row[q][0], r), bcast(row[q][1], r)};
+                acc += lr * x[q];
+            }
+            float v = ((ii == r) ? 1.f : 0.f) - (acc[0] + acc[1]);
+            if (r % 2) v -= bcast(row[r / 2][0], r) * x[r / 2][0];
+            x[r / 2][r % 2] = v * bcast(rdiag, r);
         }
         KT_UNROLL
-        for (int r = 0; r < 16; ++r)
-            Li.v[r] = rho0(r) < N ? (h ? x[(rho0(r) + 4) % N] : x[rho0(r) % N]) : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int c0 = rho0(r) % N, c1 = (rho0(r) + 4) % N;
+            Li.v[r] = rho0(r) < N ? (h ? x[c1 / 2][c1 % 2] : x[c0 / 2][c0 % 2]) : 0.f;
+        }
     }
     return ok;
 }
