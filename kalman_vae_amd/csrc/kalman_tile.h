@@ -647,7 +647,7 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
             chol<N, true>(Pn, LT, Li, dg);
             tn<N, 0>(Li, Li, Pi);
             tn<N, 0>(An, Pi, W);
-            tn<N, 0>(Pi, An, WT);
+            WT = transpose(W, lds);
             tn<N, 0>(Pf, W, J);
             KT_UNROLL
             for (int r = 0; r < 16; ++r) D.v[r] -= Pn.v[r];
@@ -663,11 +663,10 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
             // Jb = msb d^T + (G + G^T) J D and its transpose
             Tile MT, Jb, JbT;
             tn<N, 0>(J, Gsum, MT);
-            const Rows msbr = rows_of<N>(msb), dr = rows_of<N>(d);
+            const Rows msbr = rows_of<N>(msb);
             Jb = outer(1.f, msbr, d);
             tn<N, 1>(MT, D, Jb);
-            JbT = outer(1.f, dr, msb);
-            tn<N, 1>(D, MT, JbT);
+            JbT = transpose(Jb, lds);
             const float db = tv<N>(J, msb);
             Tile X1, Db;
             tn<N, 0>(G, J, X1);
@@ -677,7 +676,7 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
             store<N, N>(g.d_P + tb * N * N, G);
             Tile Wb, WbT, Anb, PibT, Z;
             tn<N, 0>(Pf, Jb, Wb);
-            tn<N, 0>(Jb, Pf, WbT);
+            WbT = transpose(Wb, lds);
             tn<N, 0>(Pi, WbT, Anb);
             store<N, N>(g.d_As + (tb + B) * N * N, Anb);
             tn<N, 0>(Wb, AnT, PibT);
@@ -732,10 +731,10 @@ KT_DEV Tile mix_t(int K, const float* __restrict__ w, const float* __restrict__ 
 
 // F, M, S^-1 and the innovation of one measurement update
 template <int N, int P>
-KT_DEV bool update_terms(const Tile& Pp, const Tile& CT, const Tile& Rm, float a, float mp, Tile& F,
-                         Tile& M, Tile& Si, float& r) {
+KT_DEV bool update_terms(const Tile& Pp, const Tile& CT, const Tile& Rm, float a, float mp,
+                         float* lds, Tile& F, Tile& M, Tile& Si, float& r) {
     tn<N, 0>(Pp, CT, F);
-    tn<N, 0>(CT, Pp, M);
+    M = transpose(F, lds);  // a transpose through LDS costs a quarter of a second product
     Tile S = Rm;
     tn<N, 1>(F, CT, S);
     Tile LT, Li;
@@ -765,7 +764,7 @@ __device__ void filter_forward_sequence(const FilterFwdArgs<float>& g, int K, in
         const float mu = g.mask ? g.mask[tb] : 1.f;
         Tile F, M, Si, X;
         float r;
-        if (!update_terms<N, P>(Pp, CT, Rm, a, mp, F, M, Si, r)) st |= ST_NONPD_INNOVATION;
+        if (!update_terms<N, P>(Pp, CT, Rm, a, mp, lds, F, M, Si, r)) st |= ST_NONPD_INNOVATION;
         const float m = mp + mu * tv<P>(M, tv<P>(Si, r));
         tn<P, 0>(Si, M, X);
         Tile Y;
@@ -860,7 +859,7 @@ __device__ void filter_backward_sequence(const FilterBwdArgs<float>& g, int b, f
         // measurement update adjoint
         Tile F, M, Si, G;
         float r;
-        update_terms<N, P>(Pp, CT, Rm, a, mp, F, M, Si, r);
+        update_terms<N, P>(Pp, CT, Rm, a, mp, lds, F, M, Si, r);
         tn<P, 0>(M, Si, G);
         const float mu = f.mask ? f.mask[tb] : 1.f;
         Tile PbT = transpose(Pb, lds);
@@ -881,10 +880,10 @@ __device__ void filter_backward_sequence(const FilterBwdArgs<float>& g, int b, f
             Pob.v[q] = mu * Pb.v[q];
             PobT.v[q] = mu * PbT.v[q];
         }
-        const Rows mobr = rows_of<N>(mob), rr = rows_of<P>(r);
-        Tile Gb = outer(1.f, mobr, r), GbT = outer(1.f, rr, mob);
+        const Rows mobr = rows_of<N>(mob);
+        Tile Gb = outer(1.f, mobr, r);
         tn<N, 2>(PobT, F, Gb);
-        tn<N, 2>(F, PobT, GbT);
+        const Tile GbT = transpose(Gb, lds);
         const float rb = tv<N>(G, mob);
         vstore<P>(g.d_a + tb * P, rb);
         const Rows rbr = rows_of<P>(rb);
@@ -893,12 +892,12 @@ __device__ void filter_backward_sequence(const FilterBwdArgs<float>& g, int b, f
         mpb -= tv<P>(C, rbr);
         Tile Mb, MbT;
         tn<N, 0>(G, Pob, Mb);
-        tn<N, 0>(Pob, G, MbT);
+        MbT = transpose(Mb, lds);
         tn<N, 2>(MbT, Pp, Cb);
         tn<P, 2>(C, Mb, Ppb);
         Tile Fb, FbT, Sib, U, Sb;
         tn<P, 0>(GbT, Si, Fb);
-        tn<P, 0>(Si, GbT, FbT);
+        FbT = transpose(Fb, lds);
         tn<N, 0>(F, Gb, Sib);
         tn<P, 0>(Sib, Si, U);
         Sb = tzero();
