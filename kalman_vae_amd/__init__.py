@@ -9,9 +9,12 @@ from .misc import aggregate
 from .dynamics_parameter_network import LSTMModel, MLPModel
 from .state_space_model import StateSpaceModel
 from .elbo import kalman_elbo
+from .variational_autoencoder import BernoulliDecoder, Encoder, GaussianDecoder
+from .kalman_vae import KalmanVariationalAutoencoder
 from .functions import (kalman_filter_steps, kalman_smooth_steps, kalman_elbo_terms,
                         read_status)
 
 __all__ = ["SampleControl", "aggregate", "LSTMModel", "MLPModel", "StateSpaceModel",
-           "kalman_elbo", "kalman_filter_steps", "kalman_smooth_steps", "kalman_elbo_terms",
+           "kalman_elbo", "KalmanVariationalAutoencoder", "Encoder", "GaussianDecoder",
+           "BernoulliDecoder", "kalman_filter_steps", "kalman_smooth_steps", "kalman_elbo_terms",
            "read_status"]

@@ -67,3 +67,30 @@ class FlatGradBucket:
                 self.flat.div_(dist.get_world_size(group))
         self.unpack()
         return self.flat
+
+
+class DataParallelStep:
+    """One data-parallel training step of a model whose loss is ``-elbo``:
+
+        step = DataParallelStep(model, optimizer)
+        objective = step(lambda: model.elbo(sample_control, xs=local_frames, ...)[0])
+
+    forward, backward, ONE all-reduce of all gradients (``FlatGradBucket``),
+    optimizer step.  Every rank holds its own slice of the batch
+    (``shard_batch``); the objective is a mean over the local batch, so
+    averaging the gradients over ranks gives the gradient of the global-batch
+    mean when the slices have equal size.  The reference trains on a single
+    device (examples/train.py) and has no counterpart of this class.
+    """
+
+    def __init__(self, model, optimizer, group=None):
+        self.model, self.optimizer, self.group = model, optimizer, group
+        self.bucket = FlatGradBucket(model.parameters())
+
+    def __call__(self, objective_fn):
+        self.optimizer.zero_grad(set_to_none=True)
+        objective = objective_fn()
+        (-objective).backward()
+        self.bucket.all_reduce(average=True, group=self.group)
+        self.optimizer.step()
+        return objective.detach()

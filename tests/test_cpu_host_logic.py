@@ -147,3 +147,31 @@ def test_aggregate_and_sample_control():
     sc = SampleControl()
     assert (sc.encoder, sc.decoder, sc.state_transition, sc.observation) == (
         "sample", "mean", "sample", "sample")
+
+
+@pytest.mark.parametrize("case", ["gaussian_lstm_f64", "bernoulli_mlp_f64"])
+def test_full_model_loads_reference_state_dict(case):
+    """KalmanVariationalAutoencoder has the reference's parameter names and shapes
+    (fixtures made from the reference's own module), and rejects bad arguments
+    before touching the GPU library."""
+    import json
+    import numpy as np
+    from kalman_vae_amd import KalmanVariationalAutoencoder, SampleControl
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "kvae", case + ".npz"))
+    cfg = json.loads(str(d["config"]))
+    model = KalmanVariationalAutoencoder(
+        image_size=tuple(cfg["image"]), image_channels=cfg["channels"], a_dim=cfg["p"],
+        z_dim=cfg["n"], K=cfg["K"], init_transition_reg_weight=0.9,
+        init_observation_reg_weight=0.9, learn_noise_covariance=True, init_noise_scale=0.7,
+        dynamics_parameter_network=cfg["net"], decoder_type=cfg["decoder"])
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}
+    assert set(sd) == set(model.state_dict())
+    model.load_state_dict(sd, strict=True)
+    with pytest.raises(ValueError):
+        model.elbo(SampleControl())
+    # encoder output on CPU is plain PyTorch: compare with the reference's encoded mean
+    if cfg["encoder"] == "mean":
+        model = model.double().eval()
+        xs = torch.from_numpy(d["in.xs"])
+        q = model.encoder(xs.reshape(-1, *xs.shape[2:]))
+        assert rel_err(q.loc.view(cfg["T"], cfg["B"], -1), torch.from_numpy(d["out.as"])) < 1e-12

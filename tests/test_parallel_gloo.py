@@ -70,3 +70,65 @@ def test_flat_bucket_allreduce_matches_full_batch(tmp_path):
                       for p in model.parameters() if p.requires_grad])
     assert got.shape == want.shape
     assert float((got - want).abs().max()) < 1e-10 * max(1.0, float(want.abs().max()))
+
+
+# -- DataParallelStep over the full model's parameters ------------------------------
+def _full_model(seed=3):
+    from kalman_vae_amd import KalmanVariationalAutoencoder
+    torch.manual_seed(seed)
+    model = KalmanVariationalAutoencoder((16, 16), 1, 2, 4, 3, 0.9, 0.9, True, 0.8, "mlp",
+                                         decoder_type="bernoulli").double()
+    xs = (torch.rand(5, 4, 1, 16, 16, dtype=torch.float64) > 0.5).double()
+    eps = torch.randn(5, 4, 4, dtype=torch.float64)
+    return model, xs, eps
+
+
+def _full_objective(model, xs, eps):
+    """Encoder mean -> Kalman objective (oracle: the package computes it on the GPU
+    only) + decoder log-likelihood, batch mean: the same composition as the model's
+    elbo, in plain PyTorch."""
+    from oracle import kalman_oracle as O
+    T, B = xs.shape[:2]
+    a = model.encoder(xs.reshape(T * B, *xs.shape[2:])).loc.view(T, B, -1)
+    ssm = model.state_space_model
+    kal, _ = O.kalman_objective(a, ssm._mat_A_K, ssm._mat_C_K, ssm.mat_Q, ssm.mat_R,
+                                ssm.initial_state_mean, ssm.initial_state_covariance,
+                                ssm.weight_model, eps, sequence_operation="mean",
+                                batch_operation="mean")
+    rec = model.decoder(a.view(T * B, -1)).log_prob(xs.reshape(T * B, *xs.shape[2:]))
+    return kal + 0.3 * rec.view(T, B, -1).sum(-1).mean()
+
+
+def _step_worker(rank, world, port, out):
+    from kalman_vae_amd.parallel import DataParallelStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, xs, eps = _full_model()
+    xs_r, eps_r = shard_batch(xs, world, rank), shard_batch(eps, world, rank)
+    step = DataParallelStep(model, torch.optim.SGD(model.parameters(), lr=0.05))
+    for _ in range(2):
+        step(lambda: _full_objective(model, xs_r, eps_r))
+    if rank == 1:       # any rank: all of them must hold the same parameters
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_matches_single_process(tmp_path):
+    from kalman_vae_amd.parallel import DataParallelStep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "params.pt")
+    mp.spawn(_step_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    model, xs, eps = _full_model()
+    step = DataParallelStep(model, torch.optim.SGD(model.parameters(), lr=0.05))
+    first = None
+    for _ in range(2):
+        obj = step(lambda: _full_objective(model, xs, eps))
+        first = obj if first is None else first
+    assert float(obj) > float(first)            # the step ascends the objective
+    for k, v in model.state_dict().items():
+        assert float((got[k] - v).abs().max()) < 1e-10 * max(1.0, float(v.abs().max())), k
