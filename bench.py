@@ -252,11 +252,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # KVAE_BENCH_REHEARSAL=1: rehearse the multi-rank code path on a box with ONE GPU
+    # (every rank on cuda:0, gloo instead of RCCL); the numbers mean nothing then.
+    rehearsal = os.environ.get("KVAE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from kalman_vae_amd import SampleControl, kalman_elbo
     from kalman_vae_amd.parallel import FlatGradBucket
@@ -315,7 +323,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -335,7 +343,8 @@ def main():
                                       if args.kernels_only else f"{args.net} weight network, ")
                                    + "filter+RTS smoother+ELBO terms fwd+bwd",
                        "seq_len": T, "batch_per_gpu": B, "global_batch": B * world,
-                       "burn_in": args.burn_in, "parallelism": f"dp{world}",
+                       "burn_in": args.burn_in,
+                       "parallelism": f"dp{world}" + (" (rehearsal: one GPU, gloo)" if rehearsal else ""),
                        "hip_graph": graphed is not None},
         }
         if graph_note:

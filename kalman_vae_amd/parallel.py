@@ -62,7 +62,14 @@ class FlatGradBucket:
         """Sum (or average) the gradients over all ranks, in place."""
         self.pack()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+                # gloo reduces host memory (its device path hangs on this ROCm build);
+                # only rehearsals and tests pair gloo with GPU tensors
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
         self.unpack()
