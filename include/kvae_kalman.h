@@ -186,6 +186,15 @@ typedef struct {
     void *d_mat_Cs;       /* (T+1,B,p,n)                                         */
     void *d_Q, *d_R;      /* summed over T and B                                 */
     void *d_m0, *d_P0;    /* summed over B                                       */
+    /* Alternative to g_obs/g_trans/g_post for the usual case that the terms only
+     * enter an aggregated objective (kvae/kalman_vae.py:244-260): when g_scale is
+     * not NULL the upstream gradient of every (t,b) entry is
+     *   w_obs * g_scale[0], w_trans * g_scale[stride], w_post * g_scale[2*stride]
+     * (g_scale: device pointer, same dtype; stride 0 = one scalar for all three) and
+     * the three per-entry tensors are ignored. */
+    const void *g_scale;
+    int32_t g_scale_stride, _pad;
+    double w_obs, w_trans, w_post;
 } kvae_elbo_bwd;
 
 int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
@@ -247,6 +256,13 @@ int kvae_lstm2_forward(int T, int B, int P, const void *x, const void *Wih0, con
                        void *gates0, void *h0, void *c0, void *gates1, void *h1, void *c1,
                        const void *h_init, const void *c_init, void *stream);
 int kvae_lstm2_backward_blocks(int B);
+/* The forward kernel's weight operands from torch.nn.LSTM's parameters
+ * (weight_hh_l0, weight_ih_l1, weight_hh_l1: (4H,H); the four bias vectors) in one
+ * launch: out (kvae_lstm2_prepared_elems() floats) = [Whh0T | Wih1T | Whh1T | b0 | b1]. */
+long kvae_lstm2_prepared_elems(void);
+int kvae_lstm2_prepare(const void *w_hh0, const void *w_ih1, const void *w_hh1, const void *b_ih0,
+                       const void *b_hh0, const void *b_ih1, const void *b_hh1, void *out,
+                       void *stream);
 int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, const void *gates0,
                         const void *c0, const void *gates1, const void *c1, const void *Wih0,
                         const void *Whh0, const void *Wih1, const void *Whh1, void *dG0, void *dG1,
@@ -255,13 +271,16 @@ int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, co
 /* Softmax head of the dynamics-parameter network, alpha = softmax(h W^T + b):
  * kvae/dynamics_parameter_network.py:57-58 (LSTMModel) and 84-90 (last layer of
  * MLPModel).  float32; h (R,H) with R = T*B rows and H in {32,64,128,256};
- * W (K,H), b (K), K <= 8; alpha (R,K).
+ * W (K,H), b (K), K <= 8; alpha (lead_rows + R, K): the first lead_rows rows are
+ * filled with 1/K (the weights the filter uses before it has seen an observation,
+ * kvae/state_space_model.py:225: pass lead_rows = B to get the (T+1,B,K) weight
+ * tensor in one piece), the softmax rows follow.
  * backward: g_alpha (R,K) gradient w.r.t. alpha; outputs d_h (R,H) and
  *   partial (kvae_softmax_head_backward_blocks(R), K*(H+1)) whose column sum
  *   over the first axis is [ dW (K,H) | db (K) ].
  */
 int kvae_softmax_head_forward(long R, int H, int K, const void *h, const void *W, const void *b,
-                              void *alpha, void *stream);
+                              void *alpha, long lead_rows, void *stream);
 int kvae_softmax_head_backward_blocks(long R);
 int kvae_softmax_head_backward(long R, int H, int K, const void *h, const void *W,
                                const void *alpha, const void *g_alpha, void *d_h, void *partial,
@@ -277,6 +296,15 @@ int kvae_softmax_head_backward(long R, int H, int K, const void *h, const void *
 int kvae_cholesky_forward(int n, int dtype, const void *A, void *L, void *status, void *stream);
 int kvae_cholesky_backward(int n, int dtype, const void *L, const void *gL, void *gA, void *stream);
 
+/* The noise covariances and the factor of R in one launch:
+ *   Q (n,n) = Lq Lq^T + q_reg I,  R (p,p) = Lr Lr^T + r_reg I   (the mat_Q / mat_R
+ *   properties, kvae/state_space_model.py:112-146),  LR (p,p) = chol(R) (null = skip).
+ * Forward values only (for steps that do not learn the noise factors).  Same limits
+ * and failure reporting as kvae_cholesky_forward.
+ */
+int kvae_noise_factors(int n, int p, int dtype, const void *Lq, const void *Lr, double q_reg,
+                       double r_reg, void *Q, void *R, void *LR, void *status, void *stream);
+
 /* Deterministic tree sums (no atomics, no memset; same bits on every run).
  * kvae_column_sum: out (cols) = column sums of the row-major (rows, cols) matrix
  *   `in` - used for the per-workgroup partial results of the backward kernels.
@@ -289,6 +317,15 @@ int kvae_column_sum(long rows, int cols, int dtype, const void *in, void *out, v
 long kvae_vector_sum_scratch_elems(int batch, long n);
 int kvae_vector_sum(int batch, long n, int dtype, const void *in, void *scratch, void *out,
                     void *stream);
+
+/* The three ELBO terms to the objective in two launches: terms (3,n) holds obs,
+ * trans, post (n = T*B entries each); out (4) = [ w_obs * sum(obs), w_trans *
+ * sum(trans), w_post * sum(post), their total ]  - aggregate() of kvae/misc.py:21-41
+ * with its constant folded into the weights, and kalman_vae.py:244-260.  scratch:
+ * kvae_weighted_terms_scratch_elems(n) elements.  Deterministic. */
+long kvae_weighted_terms_scratch_elems(long n);
+int kvae_weighted_terms(long n, int dtype, const void *terms, void *scratch, double w_obs,
+                        double w_trans, double w_post, void *out, void *stream);
 
 /* Number of memset / kernel nodes in a captured hipGraph_t (child graphs
  * included), negative on error.  Host-only helpers with no counterpart in the

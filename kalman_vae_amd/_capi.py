@@ -57,7 +57,9 @@ ElboFwd = _ptr_struct("ElboFwd", [
     "obs", "trans", "post", "z", "status"])
 ElboBwd = _ptr_struct("ElboBwd", [
     ("fwd", ElboFwd), "g_obs", "g_trans", "g_post", "d_a", "d_mean_smooth", "d_cov_smooth",
-    "d_mat_As", "d_mat_Cs", "d_Q", "d_R", "d_m0", "d_P0"])
+    "d_mat_As", "d_mat_Cs", "d_Q", "d_R", "d_m0", "d_P0", "g_scale",
+    ("g_scale_stride", C.c_int32), ("_pad", C.c_int32),
+    ("w_obs", C.c_double), ("w_trans", C.c_double), ("w_post", C.c_double)])
 
 EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
@@ -66,11 +68,13 @@ EXPORTS = (
     "kvae_elbo_forward", "kvae_elbo_backward",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
+    "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
     "kvae_softmax_head_backward_blocks",
-    "kvae_cholesky_forward", "kvae_cholesky_backward",
+    "kvae_cholesky_forward", "kvae_cholesky_backward", "kvae_noise_factors",
     "kvae_graph_count_memset_nodes", "kvae_graph_count_kernel_nodes",
     "kvae_column_sum", "kvae_vector_sum", "kvae_vector_sum_scratch_elems",
+    "kvae_weighted_terms", "kvae_weighted_terms_scratch_elems",
 )
 
 
@@ -155,19 +159,32 @@ def load():
     lib.kvae_lstm2_backward_blocks.argtypes = [C.c_int]
     lib.kvae_lstm2_backward_blocks.restype = C.c_int
     lib.kvae_lstm2_backward.restype = C.c_int
-    lib.kvae_softmax_head_forward.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 5
+    lib.kvae_softmax_head_forward.argtypes = ([C.c_long, C.c_int, C.c_int] + [_vp] * 4
+                                              + [C.c_long, _vp])
     lib.kvae_softmax_head_forward.restype = C.c_int
     lib.kvae_softmax_head_backward.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 7
     lib.kvae_softmax_head_backward.restype = C.c_int
     lib.kvae_softmax_head_backward_blocks.argtypes = [C.c_long]
     lib.kvae_softmax_head_backward_blocks.restype = C.c_int
+    lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
+    lib.kvae_lstm2_prepare.restype = C.c_int
+    lib.kvae_lstm2_prepared_elems.argtypes = []
+    lib.kvae_lstm2_prepared_elems.restype = C.c_long
     lib.kvae_cholesky_forward.argtypes = [C.c_int, C.c_int] + [_vp] * 4
     lib.kvae_cholesky_forward.restype = C.c_int
     lib.kvae_cholesky_backward.argtypes = [C.c_int, C.c_int] + [_vp] * 4
     lib.kvae_cholesky_backward.restype = C.c_int
+    lib.kvae_noise_factors.argtypes = ([C.c_int] * 3 + [_vp, _vp, C.c_double, C.c_double]
+                                       + [_vp] * 5)
+    lib.kvae_noise_factors.restype = C.c_int
     for name in ("kvae_graph_count_memset_nodes", "kvae_graph_count_kernel_nodes"):
         getattr(lib, name).argtypes = [_vp]
         getattr(lib, name).restype = C.c_int
+    lib.kvae_weighted_terms.argtypes = [C.c_long, C.c_int, _vp, _vp, C.c_double, C.c_double,
+                                        C.c_double, _vp, _vp]
+    lib.kvae_weighted_terms.restype = C.c_int
+    lib.kvae_weighted_terms_scratch_elems.argtypes = [C.c_long]
+    lib.kvae_weighted_terms_scratch_elems.restype = C.c_long
     lib.kvae_column_sum.argtypes = [C.c_long, C.c_int, C.c_int, _vp, _vp, _vp]
     lib.kvae_column_sum.restype = C.c_int
     lib.kvae_vector_sum.argtypes = [C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]

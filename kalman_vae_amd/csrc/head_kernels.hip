@@ -56,9 +56,15 @@ __device__ __forceinline__ float sum16(float v) {
 template <int H, int K>
 __global__ void __launch_bounds__(HEAD_BLOCK)
 softmax_head_forward_kernel(long R, const float* __restrict__ h, const float* __restrict__ W,
-                            const float* __restrict__ b, float* __restrict__ alpha) {
+                            const float* __restrict__ b, float* __restrict__ alpha, long lead_rows) {
     constexpr int V = H / 16;
     const int c = threadIdx.x & 15;
+    // rows 0 .. lead_rows-1 of the output are the uniform weights 1/K (the filter's
+    // weights before the first observation, kvae/state_space_model.py:225)
+    for (long i = (long)blockIdx.x * HEAD_BLOCK + threadIdx.x; i < lead_rows * K;
+         i += (long)gridDim.x * HEAD_BLOCK)
+        alpha[i] = 1.f / (float)K;
+    alpha += lead_rows * K;
     float w[K][V], bias[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -170,13 +176,13 @@ inline int head_blocks(long R, int cap) {
 
 template <int H>
 int launch_head_forward(long R, int K, const float* h, const float* W, const float* b, float* alpha,
-                        hipStream_t s) {
+                        long lead_rows, hipStream_t s) {
     const dim3 grid(head_blocks(R, HEAD_FWD_MAX_BLOCKS)), block(HEAD_BLOCK);
     switch (K) {
 #define KVAE_HF(K_)                                                                              \
     case K_:                                                                                     \
         hipLaunchKernelGGL((softmax_head_forward_kernel<H, K_>), grid, block, 0, s, R, h, W, b,  \
-                           alpha);                                                               \
+                           alpha, lead_rows);                                                    \
         return KVAE_OK;
         KVAE_HF(1) KVAE_HF(2) KVAE_HF(3) KVAE_HF(4) KVAE_HF(5) KVAE_HF(6) KVAE_HF(7) KVAE_HF(8)
 #undef KVAE_HF
@@ -209,17 +215,17 @@ int kvae_softmax_head_backward_blocks(long R) {
 }
 
 int kvae_softmax_head_forward(long R, int H, int K, const void* h, const void* W, const void* b,
-                              void* alpha, void* stream) {
-    if (R < 1 || !h || !W || !b || !alpha) return KVAE_E_BADARG;
+                              void* alpha, long lead_rows, void* stream) {
+    if (R < 1 || lead_rows < 0 || !h || !W || !b || !alpha) return KVAE_E_BADARG;
     const float *hp = (const float*)h, *wp = (const float*)W, *bp = (const float*)b;
     float* ap = (float*)alpha;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (H) {
-        case 32: rc = kvae::launch_head_forward<32>(R, K, hp, wp, bp, ap, s); break;
-        case 64: rc = kvae::launch_head_forward<64>(R, K, hp, wp, bp, ap, s); break;
-        case 128: rc = kvae::launch_head_forward<128>(R, K, hp, wp, bp, ap, s); break;
-        case 256: rc = kvae::launch_head_forward<256>(R, K, hp, wp, bp, ap, s); break;
+        case 32: rc = kvae::launch_head_forward<32>(R, K, hp, wp, bp, ap, lead_rows, s); break;
+        case 64: rc = kvae::launch_head_forward<64>(R, K, hp, wp, bp, ap, lead_rows, s); break;
+        case 128: rc = kvae::launch_head_forward<128>(R, K, hp, wp, bp, ap, lead_rows, s); break;
+        case 256: rc = kvae::launch_head_forward<256>(R, K, hp, wp, bp, ap, lead_rows, s); break;
         default: return KVAE_E_UNSUPPORTED;
     }
     if (rc != KVAE_OK) return rc;

@@ -336,7 +336,26 @@ struct ElboBwdArgs {
     const R *g_obs, *g_trans, *g_post;
     R *d_a, *d_ms, *d_Ps, *d_As, *d_Cs;
     R* partial;  // (rows, ElboParamGrads::LEN)
+    // when set, the cotangent of every entry of a term is weight * g_scale[k * stride]
+    // (the terms only feed an aggregated objective) and g_obs/g_trans/g_post are unused
+    const R* g_scale = nullptr;
+    int g_scale_stride = 0;
+    R w_obs = R(0), w_trans = R(0), w_post = R(0);
 };
+
+// upstream gradients of the three terms at pair tb
+template <typename R>
+KV_HD void elbo_cotangents(const ElboBwdArgs<R>& g, long tb, R& wo, R& wt, R& wp) {
+    if (g.g_scale) {
+        wo = g.w_obs * g.g_scale[0];
+        wt = g.w_trans * g.g_scale[g.g_scale_stride];
+        wp = g.w_post * g.g_scale[2 * g.g_scale_stride];
+    } else {
+        wo = g.g_obs ? g.g_obs[tb] : R(0);
+        wt = g.g_trans ? g.g_trans[tb] : R(0);
+        wp = g.g_post ? g.g_post[tb] : R(0);
+    }
+}
 
 template <int N, int P, int K>
 struct FilterParamGrads {
@@ -1046,9 +1065,8 @@ KV_HD void elbo_backward_pair(const ElboBwdArgs<R>& g, int t, int b, R* acc) {
     const long B = f.B;
     const int T = f.T;
     const long tb = (long)t * B + b;
-    const R wo = g.g_obs ? g.g_obs[tb] : R(0);
-    const R wt = g.g_trans ? g.g_trans[tb] : R(0);
-    const R wp = g.g_post ? g.g_post[tb] : R(0);
+    R wo, wt, wp;
+    elbo_cotangents<R>(g, tb, wo, wt, wp);
 
     R z[N], L[N * N], e[N];
     elbo_sample<R, N>(f, tb, z, L, e);
@@ -1113,7 +1131,10 @@ KV_HD void elbo_backward_pair(const ElboBwdArgs<R>& g, int t, int b, R* acc) {
     }
     // transition term of the next pair: z_t enters its mean A_{t+1} z_t
     if (t + 1 < T) {
-        const R wt1 = g.g_trans ? g.g_trans[tb + B] : R(0);
+        R wo1, wt1, wp1;   // the next pair's transition term also depends on this sample
+        elbo_cotangents<R>(g, tb + B, wo1, wt1, wp1);
+        (void)wo1;
+        (void)wp1;
         R zn[N], A[N * N], Q[N * N], LQ[N * N], u[N];
         elbo_sample<R, N>(f, tb + B, zn);
         gload<R, N * N>(f.As + (tb + B) * N * N, A);

@@ -413,9 +413,8 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
         }
         if (t < T) {
             const long tb = (long)t * B + b;
-            const float wo = g.g_obs ? g.g_obs[tb] : 0.f;
-            const float wt = g.g_trans ? g.g_trans[tb] : 0.f;
-            const float wp = g.g_post ? g.g_post[tb] : 0.f;
+            float wo, wt, wp;
+            elbo_cotangents<float>(g, tb, wo, wt, wp);
             float zb = zn_back;
             // observation term
             {

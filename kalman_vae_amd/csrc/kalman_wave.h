@@ -1103,9 +1103,8 @@ KV_HD void elbo_backward_sequence(const ElboBwdArgs<R>& g, int b, ElboBwdScratch
     vzero<R, N>(s.zn_back);  // w_{t+1} A_{t+1}^T u_{t+1}, zero for t = T-1
     for (int t = T - 1; t >= 0; --t) {
         const long tb = (long)t * B + b;
-        const R wo = g.g_obs ? g.g_obs[tb] : R(0);
-        const R wt = g.g_trans ? g.g_trans[tb] : R(0);
-        const R wp = g.g_post ? g.g_post[tb] : R(0);
+        R wo, wt, wp;
+        elbo_cotangents<R>(g, tb, wo, wt, wp);
         elbo_sample<R, N, P>(f, tb, s);  // s.z, s.L, s.e
         vcopy<R, N>(s.zn_back, s.zb);
         // observation term

@@ -176,6 +176,11 @@ ElboBwdArgs<R> make_args(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws) 
     g.g_obs = (const R*)io->g_obs;
     g.g_trans = (const R*)io->g_trans;
     g.g_post = (const R*)io->g_post;
+    g.g_scale = (const R*)io->g_scale;
+    g.g_scale_stride = io->g_scale_stride;
+    g.w_obs = (R)io->w_obs;
+    g.w_trans = (R)io->w_trans;
+    g.w_post = (R)io->w_post;
     g.d_a = (R*)io->d_a;
     g.d_ms = (R*)io->d_mean_smooth;
     g.d_Ps = (R*)io->d_cov_smooth;

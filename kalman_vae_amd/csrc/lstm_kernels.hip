@@ -979,9 +979,60 @@ inline bool lstm2_use_16_row_tiles(int B) {
     return (B + 31) / 32 < 256;
 }
 
+// Operands of the persistent forward kernel from the module's parameters in one
+// launch: the three (4H,H) matrices transposed to (H,4H) and the two summed bias
+// vectors, packed as [Whh0T | Wih1T | Whh1T | b0 | b1].  Five library launches
+// (three transposed copies, two additions) otherwise, every training step.
+constexpr int PREP_TILES = (PG4 / 32) * (PH / 32);
+__global__ void __launch_bounds__(256)
+lstm2_prepare_kernel(const float* __restrict__ w_hh0, const float* __restrict__ w_ih1,
+                     const float* __restrict__ w_hh1, const float* __restrict__ b_ih0,
+                     const float* __restrict__ b_hh0, const float* __restrict__ b_ih1,
+                     const float* __restrict__ b_hh1, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (b == 3 * PREP_TILES) {
+        float* b0 = out + 3 * PH * PG4;
+        for (int e = threadIdx.x; e < PG4; e += 256) {
+            b0[e] = b_ih0[e] + b_hh0[e];
+            b0[PG4 + e] = b_ih1[e] + b_hh1[e];
+        }
+        return;
+    }
+    const int m = b / PREP_TILES, t = b % PREP_TILES, tr = t / (PH / 32), tc = t % (PH / 32);
+    const float* src = m == 0 ? w_hh0 : (m == 1 ? w_ih1 : w_hh1);
+    float* dst = out + (long)m * PH * PG4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        tile[r][tx] = src[(32 * tr + r) * PH + 32 * tc + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        dst[(32 * tc + r) * PG4 + 32 * tr + tx] = tile[tx][r];
+    }
+}
+
 }  // namespace kvae
 
 extern "C" {
+
+long kvae_lstm2_prepared_elems(void) { return 3L * kvae::PH * kvae::PG4 + 2L * kvae::PG4; }
+
+int kvae_lstm2_prepare(const void* w_hh0, const void* w_ih1, const void* w_hh1, const void* b_ih0,
+                       const void* b_hh0, const void* b_ih1, const void* b_hh1, void* out,
+                       void* stream) {
+    if (!w_hh0 || !w_ih1 || !w_hh1 || !b_ih0 || !b_hh0 || !b_ih1 || !b_hh1 || !out)
+        return KVAE_E_BADARG;
+    hipLaunchKernelGGL(kvae::lstm2_prepare_kernel, dim3(3 * kvae::PREP_TILES + 1), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)w_hh0, (const float*)w_ih1,
+                       (const float*)w_hh1, (const float*)b_ih0, (const float*)b_hh0,
+                       (const float*)b_ih1, (const float*)b_hh1, (float*)out);
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
 
 int kvae_lstm2_forward(int T, int B, int P, const void* x, const void* Wih0, const void* b0,
                        const void* Whh0T, const void* Wih1T, const void* Whh1T, const void* b1,

@@ -91,6 +91,51 @@ void launch_vector_sum(int batch, long n, const T* in, T* scratch, T* out, hipSt
                        chunks, (const T*)scratch, out);
 }
 
+// Second level of the three-term total: out[k] = w[k] * (sum of partial[k][0..chunks)),
+// out[3] = out[0] + out[1] + out[2]  (the aggregate() of the three ELBO terms and the
+// weighted objective kalman_weight * (obs + trans - post), kvae/kalman_vae.py:244-260).
+struct TermWeights {
+    double w[3];
+};
+template <typename T>
+__global__ void __launch_bounds__(VECSUM_BLOCK)
+weighted_terms_kernel(long chunks, const T* __restrict__ partial, TermWeights tw,
+                      T* __restrict__ out) {
+    __shared__ T sm[3][VECSUM_BLOCK / 64];
+    for (int k = 0; k < 3; ++k) {
+        T acc = T(0);
+        for (long i = threadIdx.x; i < chunks; i += VECSUM_BLOCK) acc += partial[k * chunks + i];
+        acc = wave_sum<T>(acc);
+        if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T total = T(0);
+        for (int k = 0; k < 3; ++k) {
+            T t = T(0);
+#pragma unroll
+            for (int w = 0; w < VECSUM_BLOCK / 64; ++w) t += sm[k][w];
+            t *= (T)tw.w[k];
+            out[k] = t;
+            total += t;
+        }
+        out[3] = total;
+    }
+}
+
+template <typename T>
+void launch_weighted_terms(long n, const T* terms, T* scratch, const double* w, T* out,
+                           hipStream_t s) {
+    const long chunks = vecsum_chunks(n);
+    const long chunk = (n + chunks - 1) / chunks;
+    hipLaunchKernelGGL((chunk_sum_kernel<T>), dim3((unsigned)chunks, 3), dim3(VECSUM_BLOCK), 0, s, n,
+                       chunk, terms, scratch);
+    TermWeights tw;
+    for (int k = 0; k < 3; ++k) tw.w[k] = w[k];
+    hipLaunchKernelGGL((weighted_terms_kernel<T>), dim3(1), dim3(VECSUM_BLOCK), 0, s, chunks,
+                       (const T*)scratch, tw, out);
+}
+
 }  // namespace kvae
 
 extern "C" {
@@ -126,6 +171,23 @@ int kvae_vector_sum(int batch, long n, int dtype, const void* in, void* scratch,
     else if (dtype == KVAE_F64)
         kvae::launch_vector_sum<double>(batch, n, (const double*)in, (double*)scratch, (double*)out,
                                         s);
+    else
+        return KVAE_E_BADARG;
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+long kvae_weighted_terms_scratch_elems(long n) { return n < 1 ? 0 : 3 * kvae::vecsum_chunks(n); }
+
+int kvae_weighted_terms(long n, int dtype, const void* terms, void* scratch, double w_obs,
+                        double w_trans, double w_post, void* out, void* stream) {
+    if (n < 1 || !terms || !scratch || !out) return KVAE_E_BADARG;
+    const double w[3] = {w_obs, w_trans, w_post};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KVAE_F32)
+        kvae::launch_weighted_terms<float>(n, (const float*)terms, (float*)scratch, w, (float*)out, s);
+    else if (dtype == KVAE_F64)
+        kvae::launch_weighted_terms<double>(n, (const double*)terms, (double*)scratch, w,
+                                            (double*)out, s);
     else
         return KVAE_E_BADARG;
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;

@@ -91,9 +91,79 @@ small_cholesky_backward_kernel(int n, const T* __restrict__ L, const T* __restri
     }
 }
 
+// Q = Lq Lq^T + q_reg I,  R = Lr Lr^T + r_reg I  and  LR = chol(R)
+// (kvae/state_space_model.py:112-146 and the factor the smoother's observation
+// noise needs) in ONE launch of two single-wavefront workgroups: workgroup 0
+// forms Q, workgroup 1 forms R and factors it.  As separate library calls these
+// are seven launches of a few microseconds each per training step.  Forward only:
+// callers that differentiate through the noise factors use the separate
+// operations.
+template <typename T, int MAXN>
+__global__ void __launch_bounds__(64)
+noise_factors_kernel(int n, int p, const T* __restrict__ Lq, const T* __restrict__ Lr, T q_reg,
+                     T r_reg, T* __restrict__ Q, T* __restrict__ R, T* __restrict__ LR,
+                     int* status) {
+    __shared__ T f[MAXN * (MAXN + 1)];
+    __shared__ T s[MAXN * (MAXN + 1)];
+    const bool second = blockIdx.x == 1;
+    const int d = second ? p : n, ld = d + 1, i = threadIdx.x;
+    const T* F = second ? Lr : Lq;
+    const T reg = second ? r_reg : q_reg;
+    T* out = second ? R : Q;
+    for (int e = i; e < d * d; e += 64) f[(e / d) * ld + e % d] = F[e];
+    __syncthreads();
+    for (int e = i; e < d * d; e += 64) {
+        const int r = e / d, c = e % d;
+        T acc = r == c ? reg : T(0);
+        for (int k = 0; k < d; ++k) acc += f[r * ld + k] * f[c * ld + k];
+        s[r * ld + c] = acc;
+        out[e] = acc;
+    }
+    __syncthreads();
+    if (!second || !LR) return;
+    bool bad = false;
+    for (int j = 0; j < d; ++j) {
+        T acc = T(0);
+        if (i >= j && i < d) {
+            acc = s[i * ld + j];
+            for (int k = 0; k < j; ++k) acc -= s[i * ld + k] * s[j * ld + k];
+        }
+        __syncthreads();
+        if (i == j) {
+            if (!(acc > T(0))) bad = true;
+            s[j * ld + j] = sqrt(acc);
+        }
+        __syncthreads();
+        if (i > j && i < d) s[i * ld + j] = acc / s[j * ld + j];
+        __syncthreads();
+    }
+    for (int e = i; e < d * d; e += 64) {
+        const int r = e / d, c = e % d;
+        LR[e] = c <= r ? s[r * ld + c] : T(0);
+    }
+    if (bad && status) atomicOr(status, 8);
+}
+
 }  // namespace kvae
 
 extern "C" {
+
+int kvae_noise_factors(int n, int p, int dtype, const void* Lq, const void* Lr, double q_reg,
+                       double r_reg, void* Q, void* R, void* LR, void* status, void* stream) {
+    if (n < 1 || p < 1 || !Lq || !Lr || !Q || !R) return KVAE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == KVAE_F32 && n <= 64 && p <= 64)
+        hipLaunchKernelGGL((kvae::noise_factors_kernel<float, 64>), dim3(2), dim3(64), 0, s, n, p,
+                           (const float*)Lq, (const float*)Lr, (float)q_reg, (float)r_reg, (float*)Q,
+                           (float*)R, (float*)LR, (int*)status);
+    else if (dtype == KVAE_F64 && n <= 32 && p <= 32)
+        hipLaunchKernelGGL((kvae::noise_factors_kernel<double, 32>), dim3(2), dim3(64), 0, s, n, p,
+                           (const double*)Lq, (const double*)Lr, q_reg, r_reg, (double*)Q, (double*)R,
+                           (double*)LR, (int*)status);
+    else
+        return KVAE_E_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
 
 int kvae_cholesky_forward(int n, int dtype, const void* A, void* L, void* status, void* stream) {
     if (n < 1 || n > kvae::CHOL_MAX_N || !A || !L) return KVAE_E_BADARG;

@@ -23,12 +23,23 @@ class LSTMModel(nn.Module):
         self.num_layers = num_layers
         self.lstm = nn.LSTM(input_dim, hidden_dim, num_layers=num_layers)
         self.linear = nn.Linear(hidden_dim, output_dim)
-        self.hidden = None
+        self._hidden = None
         self.count = 0
         # whole-sequence calls on a GPU run the recurrence on the package's HIP
         # kernels (float32, hidden_dim a multiple of 32); step-by-step calls and
         # everything else use torch.nn.LSTM
         self.use_hip_recurrence = True
+
+    @property
+    def hidden(self):
+        """(h_n, c_n) carried between calls, each (num_layers, B, hidden_dim), or None."""
+        if isinstance(self._hidden, lstm_function.LastState):
+            self._hidden = self._hidden.get()
+        return self._hidden
+
+    @hidden.setter
+    def hidden(self, value):
+        self._hidden = value
 
     def clear_hidden_state(self):
         self.hidden = None
@@ -40,24 +51,27 @@ class LSTMModel(nn.Module):
                        torch.zeros(shape, dtype=dtype, device=device))
         self.count = 0
 
-    def forward(self, x):
+    def forward(self, x, lead=False):
+        """x (t,B,a_dim) -> weights (t,B,K); lead=True prepends the uniform weights
+        of the step before the first observation: (t+1,B,K)."""
         self.count += 1
         if (self.use_hip_recurrence and self.hidden is None and x.size(0) > 1
                 and lstm_function.supported(x, self.hidden_dim)):
             # whole sequence from a fresh state: recurrence on the HIP kernels
             h, hidden = lstm_function.fused_lstm(x, self.lstm)
-            self.hidden = (hidden[0].detach(), hidden[1].detach())
-            return lstm_function.softmax_head(h, self.linear)
+            self.hidden = (hidden if isinstance(hidden, lstm_function.LastState)
+                           else (hidden[0].detach(), hidden[1].detach()))
+            return lstm_function.softmax_head(h, self.linear, lead)
         if (self.use_hip_recurrence and not torch.is_grad_enabled()
                 and lstm_function.persistent_supported(x, self.lstm)):
             # inference from the carried state (the step-by-step masked filter): the
             # persistent kernel continues from self.hidden, no library RNN call
             h, self.hidden = lstm_function.lstm2_nograd(x, self.lstm, self.hidden)
-            return lstm_function.softmax_head(h, self.linear)
+            return lstm_function.softmax_head(h, self.linear, lead)
         if self.hidden is None:
             self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
         h, self.hidden = self.lstm(x, self.hidden)
-        return lstm_function.softmax_head(h, self.linear)
+        return lstm_function.softmax_head(h, self.linear, lead)
 
     is_recurrent = True
 
@@ -85,11 +99,11 @@ class MLPModel(nn.Module):
     def reset_hidden_state(self, batch_size, device, dtype):
         pass
 
-    def forward(self, x):
+    def forward(self, x, lead=False):
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
             if i == last:
-                return lstm_function.softmax_head(x, layer)
+                return lstm_function.softmax_head(x, layer, lead)
             x = torch.relu(layer(x))
 
     is_recurrent = False

@@ -33,6 +33,28 @@ def kalman_elbo(
     ssm = state_space_model
     T, B = as_.shape[:2]
     _validate_shape(as_, (T, B, ssm.a_dim), "as_")
+    eps = None
+    if not ssm.rng_parity and observation_mask is None:
+        # free draw order: all the noise of the step (smoother state and observation
+        # noise, ELBO sample) in ONE launch, handed out as contiguous pieces
+        st, ob = ssm._modes(sample_control, filtering=False)
+        shapes = ([(T, B, ssm.z_dim)] if st else []) + ([(T, B, ssm.a_dim)] if ob else [])
+        shapes.append((T, B, ssm.z_dim))
+        sizes = [s[0] * s[1] * s[2] for s in shapes]
+        flat = _standard_normal((sum(sizes),), dtype=as_.dtype, device=as_.device)
+        pieces = [piece.view(shape) for piece, shape in zip(flat.split(sizes), shapes)]
+        ssm._noise_pool, eps = pieces[:-1], pieces[-1]
+    try:
+        return _kalman_elbo(ssm, as_, sample_control, observation_mask, kalman_weight,
+                            learn_weight_model, symmetrize_covariance, burn_in,
+                            sequence_operation, batch_operation, eps)
+    finally:
+        ssm._noise_pool = None
+
+
+def _kalman_elbo(ssm, as_, sample_control, observation_mask, kalman_weight, learn_weight_model,
+                 symmetrize_covariance, burn_in, sequence_operation, batch_operation, eps):
+    T, B = as_.shape[:2]
     with ssm.cached_matrices():     # Q, R and chol(R) are formed once for the whole step
         (filter_means, filter_covariances, filter_next_means, filter_next_covariances,
          mat_As, mat_Cs, filter_as, weights) = ssm.kalman_filter(
@@ -46,20 +68,19 @@ def kalman_elbo(
             symmetrize_covariance=symmetrize_covariance, burn_in=burn_in)
 
         # zs_distrib.rsample(): one (T,B,n) standard-normal draw, always sampled
-        eps = _standard_normal((T, B, ssm.z_dim), dtype=as_.dtype, device=as_.device)
-        obs, trans, post, _ = F.kalman_elbo_terms(
+        if eps is None:
+            eps = _standard_normal((T, B, ssm.z_dim), dtype=as_.dtype, device=as_.device)
+        # aggregate(v) (kvae/misc.py:21-41) is a constant times the total of v: the
+        # constant, kalman_weight and the minus sign of the posterior term
+        # (kalman_vae.py:244-260) are the three weights of one fused node
+        c = kalman_weight * aggregate_weights(T, B, sequence_operation, batch_operation)
+        objective, weighted, terms, _ = F.kalman_elbo_objective(
             as_, means, covariances, mat_As, mat_Cs, ssm.mat_Q, ssm.mat_R,
-            ssm.initial_state_mean, ssm.initial_state_covariance, eps)
+            ssm.initial_state_mean, ssm.initial_state_covariance, eps, c, c, -c)
     if ssm.check_numerics:
         F.raise_on_status(as_.device)
-    # aggregate(v) (kvae/misc.py:21-41) is a constant times the total of v; the three
-    # totals are one deterministic tree sum on the HIP library, the weights
-    # (kalman_weight, and the minus sign of the posterior term, kalman_vae.py:244-260)
-    # one multiplication by a constant vector
-    c = kalman_weight * aggregate_weights(T, B, sequence_operation, batch_operation)
-    weighted = F.term_totals(obs, trans, post) * F.constant_vector((c, c, -c), obs)
+    obs, trans, post = terms[0], terms[1], terms[2]
     w_obs, w_trans, w_post = weighted[0], weighted[1], weighted[2]
-    objective = weighted.sum()
     info = {
         "kalman_weight": kalman_weight,
         "kalman_observation_log_likelihood": w_obs,

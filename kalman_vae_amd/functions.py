@@ -96,6 +96,19 @@ class SmallCholeskyFunction(torch.autograd.Function):
         return gA
 
 
+def noise_factors(Lq, Lr, q_reg, r_reg):
+    """(Q, R, chol(R)) = (Lq Lq^T + q_reg I, Lr Lr^T + r_reg I, chol(R)) in one launch,
+    values only (no autograd graph): kvae/state_space_model.py:112-146."""
+    capi.require_gpu(Lq)
+    Lq, Lr = Lq.detach().contiguous(), Lr.detach().contiguous()
+    Q, R, LR = torch.empty_like(Lq), torch.empty_like(Lr), torch.empty_like(Lr)
+    capi.check(capi.load().kvae_noise_factors(
+        Lq.shape[0], Lr.shape[0], capi.dtype_code(Lq.dtype), Lq.data_ptr(), Lr.data_ptr(),
+        float(q_reg), float(r_reg), Q.data_ptr(), R.data_ptr(), LR.data_ptr(),
+        status_word(Lq.device).data_ptr(), capi.current_stream_ptr()))
+    return Q, R, LR
+
+
 def cholesky_factor(A):
     if A.dim() != 2 or A.shape[0] != A.shape[1]:
         raise ValueError("cholesky_factor expects one square matrix")
@@ -337,6 +350,69 @@ class KalmanElboFunction(torch.autograd.Function):
         return d_a, d_ms, d_Ps, d_As, d_Cs, d_Q, d_R, d_m0, d_P0, None
 
 
+class KalmanElboObjectiveFunction(torch.autograd.Function):
+    """The three ELBO terms AND their aggregation in one autograd node:
+    (a, mean_smooth, cov_smooth, mat_As, mat_Cs, Q, R, m0, P0, eps; w_obs, w_trans,
+    w_post) -> objective = w_obs sum(obs) + w_trans sum(trans) + w_post sum(post)
+    (kvae/kalman_vae.py:191-260 with aggregate()'s constant folded into the weights),
+    the three weighted totals (3,), the un-aggregated terms (3,T,B) and the sample z
+    (both values only).  The backward pass hands the kernel one scalar per term instead
+    of three (T,B) cotangent tensors, so neither pass runs any elementwise glue."""
+
+    @staticmethod
+    def forward(ctx, a, ms, Ps, As, Cs, Q, R, m0, P0, eps, w_obs, w_trans, w_post):
+        capi.require_gpu(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+        a, ms, Ps, As, Cs, Q, R, m0, P0, eps = map(_c, (a, ms, Ps, As, Cs, Q, R, m0, P0, eps))
+        lib = capi.load()
+        T, B, n = ms.shape
+        p = a.shape[2]
+        dims = _dims(T, B, n, p, _any_K(n, p), a.dtype, True, 0)
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        terms, z, out = new(3, T, B), new(T, B, n), new(4)
+        io = capi.fill(capi.ElboFwd(), a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs,
+                       Q=Q, R=R, m0=m0, P0=P0, eps=eps, obs=terms[0], trans=terms[1],
+                       post=terms[2], z=z, status=status_word(a.device))
+        stream = capi.current_stream_ptr()
+        capi.check(lib.kvae_elbo_forward(C.byref(dims), C.byref(io), stream))
+        scratch = new(lib.kvae_weighted_terms_scratch_elems(T * B))
+        capi.check(lib.kvae_weighted_terms(T * B, capi.dtype_code(a.dtype), terms.data_ptr(),
+                                           scratch.data_ptr(), w_obs, w_trans, w_post,
+                                           out.data_ptr(), stream))
+        ctx.save_for_backward(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+        ctx.dims, ctx.weights = dims, (float(w_obs), float(w_trans), float(w_post))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(terms, z)
+        return out[3], out[:3], terms, z
+
+    @staticmethod
+    def backward(ctx, g_objective, g_weighted, _g_terms, _g_z):
+        if g_objective is None and g_weighted is None:
+            return (None,) * 13
+        a, ms, Ps, As, Cs, Q, R, m0, P0, eps = ctx.saved_tensors
+        if g_weighted is None:
+            scale, stride = g_objective.contiguous(), 0
+        else:
+            scale = g_weighted if g_objective is None else g_weighted + g_objective
+            scale, stride = scale.contiguous(), 1
+        dims = ctx.dims
+        T, B, n, p = dims.T, dims.B, dims.n, dims.p
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        d_a, d_ms, d_Ps = new(T, B, p), new(T, B, n), new(T, B, n, n)
+        d_As, d_Cs = new(T + 1, B, n, n), new(T + 1, B, p, n)
+        d_Q, d_R, d_m0, d_P0 = new(n, n), new(p, p), new(n), new(n, n)
+        io = capi.ElboBwd()
+        capi.fill(io.fwd, a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs, Q=Q, R=R,
+                  m0=m0, P0=P0, eps=eps)
+        capi.fill(io, g_scale=scale, g_scale_stride=stride, d_a=d_a, d_mean_smooth=d_ms,
+                  d_cov_smooth=d_Ps, d_mat_As=d_As, d_mat_Cs=d_Cs, d_Q=d_Q, d_R=d_R, d_m0=d_m0,
+                  d_P0=d_P0)
+        io.w_obs, io.w_trans, io.w_post = ctx.weights
+        ws, nbytes = _workspace(dims, capi.OP_ELBO_BWD, a.device)
+        capi.check(capi.load().kvae_elbo_backward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                  nbytes, capi.current_stream_ptr()))
+        return d_a, d_ms, d_Ps, d_As, d_Cs, d_Q, d_R, d_m0, d_P0, None, None, None, None
+
+
 def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,
                         want_mats=True):
     return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,
@@ -351,6 +427,12 @@ def kalman_smooth_steps(m, P, mn, Pn, As, Cs, LR=None, eps_state=None, eps_obs=N
 
 def kalman_elbo_terms(a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
     return KalmanElboFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+
+
+def kalman_elbo_objective(a, ms, Ps, As, Cs, Q, R, m0, P0, eps, w_obs, w_trans, w_post):
+    """(objective, weighted totals (3,), terms (3,T,B), z): see KalmanElboObjectiveFunction."""
+    return KalmanElboObjectiveFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps, float(w_obs),
+                                             float(w_trans), float(w_post))
 
 
 @torch.no_grad()

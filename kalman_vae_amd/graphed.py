@@ -36,6 +36,7 @@ class GraphedElboStep:
         self._kwargs = dict(elbo_kwargs)
         self._sc = sample_control
         self._checked = ssm.check_numerics
+        self._minus_one = None
         ssm.check_numerics = False
         try:
             side = torch.cuda.Stream(device=as_example.device)
@@ -76,7 +77,11 @@ class GraphedElboStep:
         self.ssm.zero_grad(set_to_none=True)
         self.static_as.grad = None
         objective, _ = kalman_elbo(self.ssm, self.static_as, self._sc, **self._kwargs)
-        (-objective).backward()
+        # gradients of the loss -objective: a constant -1 as the upstream gradient
+        # instead of a negation kernel, its adjoint and the seed fill
+        if self._minus_one is None:
+            self._minus_one = torch.full((), -1.0, dtype=objective.dtype, device=objective.device)
+        objective.backward(self._minus_one)
         return objective.detach()
 
     def __call__(self, as_=None):

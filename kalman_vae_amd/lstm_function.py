@@ -70,10 +70,11 @@ class FusedLSTMFunction(torch.autograd.Function):
         ctx.L, ctx.H = L, H
         h_n, c_n = torch.stack(h_n), torch.stack(c_n)
         ctx.mark_non_differentiable(h_n, c_n)
+        ctx.set_materialize_grads(False)
         return inp, h_n, c_n
 
     @staticmethod
-    def backward(ctx, dh_top, _dhn, _dcn):
+    def backward(ctx, dh_top, _dhn, _dcn):  # the state outputs carry no gradient
         lib = capi.load()
         L, H = ctx.L, ctx.H
         tensors = ctx.saved_tensors
@@ -108,6 +109,21 @@ class FusedLSTMFunction(torch.autograd.Function):
         return (dx, *grads)
 
 
+def _lstm2_operands(w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+    """(Whh0T, Wih1T, Whh1T, b0, b1) for the persistent forward kernel, built by one
+    launch into one buffer (views of it are returned)."""
+    lib = capi.load()
+    H, G = 128, 512
+    buf = torch.empty(lib.kvae_lstm2_prepared_elems(), dtype=w_hh0.dtype, device=w_hh0.device)
+    capi.check(lib.kvae_lstm2_prepare(
+        w_hh0.contiguous().data_ptr(), w_ih1.contiguous().data_ptr(),
+        w_hh1.contiguous().data_ptr(), b_ih0.contiguous().data_ptr(),
+        b_hh0.contiguous().data_ptr(), b_ih1.contiguous().data_ptr(),
+        b_hh1.contiguous().data_ptr(), buf.data_ptr(), capi.current_stream_ptr()))
+    mats = buf[:3 * H * G].view(3, H, G)
+    return mats[0], mats[1], mats[2], buf[3 * H * G:3 * H * G + G], buf[3 * H * G + G:]
+
+
 class FusedLSTM2Function(torch.autograd.Function):
     """Two layers, hidden size 128, input dimension <= 4: the persistent kernels
     (one launch for all T steps of both layers, forward and backward)."""
@@ -121,19 +137,23 @@ class FusedLSTM2Function(torch.autograd.Function):
         new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
         gates0, h0, c0 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
         gates1, h1, c1 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
-        keep = (w_ih0.contiguous(), b_ih0 + b_hh0, w_hh0.t().contiguous(),
-                w_ih1.t().contiguous(), w_hh1.t().contiguous(), b_ih1 + b_hh1)
+        whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1,
+                                                      b_hh1)
+        keep = (w_ih0.contiguous(), b0, whh0t, wih1t, whh1t, b1)
         capi.check(lib.kvae_lstm2_forward(
             T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), gates0.data_ptr(),
             h0.data_ptr(), c0.data_ptr(), gates1.data_ptr(), h1.data_ptr(), c1.data_ptr(),
             None, None, capi.current_stream_ptr()))
         ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
-        h_n, c_n = torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]])
-        ctx.mark_non_differentiable(h_n, c_n)
-        return h1, h_n, c_n
+        # the lower layer's h and both cell sequences go out too (not differentiable):
+        # their last steps are the state a later call continues from, and the caller
+        # assembles it only if such a call comes
+        ctx.mark_non_differentiable(h0, c0, c1)
+        ctx.set_materialize_grads(False)
+        return h1, h0, c0, c1
 
     @staticmethod
-    def backward(ctx, g_h1, _dhn, _dcn):
+    def backward(ctx, g_h1, _dh0, _dc0, _dc1):
         lib = capi.load()
         x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
         T, B, P = x.shape
@@ -161,20 +181,26 @@ class FusedLSTM2Function(torch.autograd.Function):
 
 
 class SoftmaxHeadFunction(torch.autograd.Function):
-    """softmax(h @ W^T + b) over the last axis: h (..., H), W (K, H), b (K)."""
+    """softmax(h @ W^T + b) over the last axis: h (..., H), W (K, H), b (K).  With
+    lead = True and h (T,B,H) the result is (T+1,B,K) whose first step is the
+    uniform 1/K (written by the same launch)."""
 
     @staticmethod
-    def forward(ctx, h, W, b):
+    def forward(ctx, h, W, b, lead):
         lib = capi.load()
         H, K = h.shape[-1], W.shape[0]
         h2, Wc = h.contiguous().view(-1, H), W.contiguous()
-        alpha = torch.empty(h2.shape[0], K, dtype=h.dtype, device=h.device)
+        lead_rows = h.shape[1] if lead else 0
+        out = torch.empty(lead_rows + h2.shape[0], K, dtype=h.dtype, device=h.device)
         capi.check(lib.kvae_softmax_head_forward(h2.shape[0], H, K, h2.data_ptr(), Wc.data_ptr(),
-                                                 b.contiguous().data_ptr(), alpha.data_ptr(),
-                                                 capi.current_stream_ptr()))
+                                                 b.contiguous().data_ptr(), out.data_ptr(),
+                                                 lead_rows, capi.current_stream_ptr()))
+        alpha = out[lead_rows:]
         ctx.save_for_backward(h2, Wc, alpha)
-        ctx.lead = h.shape[:-1]
-        return alpha.view(*h.shape[:-1], K)
+        ctx.lead, ctx.lead_rows = h.shape[:-1], lead_rows
+        if lead:
+            return out.view(h.shape[0] + 1, h.shape[1], K)
+        return out.view(*h.shape[:-1], K)
 
     @staticmethod
     def backward(ctx, g):
@@ -182,7 +208,7 @@ class SoftmaxHeadFunction(torch.autograd.Function):
         h2, Wc, alpha = ctx.saved_tensors
         R, H = h2.shape
         K = Wc.shape[0]
-        g2 = g.contiguous().view(R, K)
+        g2 = g.contiguous().view(-1, K)[ctx.lead_rows:]
         d_h = torch.empty_like(h2)
         partial = torch.empty(lib.kvae_softmax_head_backward_blocks(R), K * (H + 1),
                               dtype=h2.dtype, device=h2.device)
@@ -190,7 +216,7 @@ class SoftmaxHeadFunction(torch.autograd.Function):
                                                   alpha.data_ptr(), g2.data_ptr(), d_h.data_ptr(),
                                                   partial.data_ptr(), capi.current_stream_ptr()))
         sums = capi.column_sum(partial)
-        return d_h.view(*ctx.lead, H), sums[:K * H].view(K, H), sums[K * H:]
+        return d_h.view(*ctx.lead, H), sums[:K * H].view(K, H), sums[K * H:], None
 
 
 def head_supported(h, linear):
@@ -198,12 +224,18 @@ def head_supported(h, linear):
             and linear.out_features <= 8 and linear.bias is not None)
 
 
-def softmax_head(h, linear):
+def softmax_head(h, linear, lead=False):
     """softmax(linear(h), dim=-1) for a torch.nn.Linear with few outputs: the HIP
-    head kernels on a GPU in float32, plain torch otherwise."""
+    head kernels on a GPU in float32, plain torch otherwise.  lead=True (h (T,B,H))
+    prepends one step of uniform weights 1/K: result (T+1,B,K)."""
     if head_supported(h, linear):
-        return SoftmaxHeadFunction.apply(h, linear.weight, linear.bias)
-    return torch.softmax(linear(h), dim=-1)
+        return SoftmaxHeadFunction.apply(h, linear.weight, linear.bias, lead)
+    alpha = torch.softmax(linear(h), dim=-1)
+    if lead:
+        first = torch.full((1,) + tuple(alpha.shape[1:]), 1.0 / alpha.shape[-1], dtype=alpha.dtype,
+                           device=alpha.device)
+        alpha = torch.cat([first, alpha], dim=0)
+    return alpha
 
 
 def persistent_supported(x, lstm):
@@ -224,9 +256,10 @@ def lstm2_nograd(x, lstm, hidden=None):
     new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
     h0, c0, h1, c1 = new(T, B, H), new(T, B, H), new(T, B, H), new(T, B, H)
     w = lambda n: getattr(lstm, n)
-    keep = (w("weight_ih_l0").contiguous(), w("bias_ih_l0") + w("bias_hh_l0"),
-            w("weight_hh_l0").t().contiguous(), w("weight_ih_l1").t().contiguous(),
-            w("weight_hh_l1").t().contiguous(), w("bias_ih_l1") + w("bias_hh_l1"))
+    whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(
+        w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
+        w("bias_ih_l1"), w("bias_hh_l1"))
+    keep = (w("weight_ih_l0").contiguous(), b0, whh0t, wih1t, whh1t, b1)
     h_init = c_init = None
     if hidden is not None:
         h_init, c_init = hidden[0].contiguous(), hidden[1].contiguous()
@@ -245,7 +278,28 @@ def fused_lstm(x, lstm):
         params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
                    getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
     if lstm.num_layers == 2 and lstm.hidden_size == 128 and x.shape[2] <= 4 and PERSISTENT:
-        out, h_n, c_n = FusedLSTM2Function.apply(x, *params)
-    else:
-        out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
+        out, h0, c0, c1 = FusedLSTM2Function.apply(x, *params)
+        return out, LastState((h0[-1], out.detach()[-1]), (c0[-1], c1[-1]))
+    out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
     return out, (h_n, c_n)
+
+
+class LastState:
+    """(h_n, c_n) of a whole-sequence call, stacked over the layers only when
+    something asks for it (a training step never does)."""
+
+    def __init__(self, h_layers, c_layers):
+        self._h, self._c, self._value = h_layers, c_layers, None
+
+    def get(self):
+        if self._value is None:
+            self._value = (torch.stack([t.detach() for t in self._h]),
+                           torch.stack([t.detach() for t in self._c]))
+            self._h = self._c = None
+        return self._value
+
+    def __iter__(self):
+        return iter(self.get())
+
+    def __getitem__(self, i):
+        return self.get()[i]

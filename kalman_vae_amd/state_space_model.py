@@ -83,6 +83,7 @@ class StateSpaceModel(nn.Module):
                                               hidden_dim, num_layers)
         # behaviour switches that have no counterpart in the reference
         self._matrix_cache = None   # see cached_matrices()
+        self._noise_pool = None     # see _draw()
         self.rng_parity = True      # draw noise exactly like the reference does
         self.check_numerics = True  # raise on a non-positive-definite covariance (host sync)
 
@@ -123,6 +124,13 @@ class StateSpaceModel(nn.Module):
         Only valid while the parameters are not modified, i.e. inside one step."""
         outer = self._matrix_cache
         self._matrix_cache = {} if outer is None else outer
+        noise_is_constant = (self.fix_matrices or not self.learn_noise_covariance
+                             or not torch.is_grad_enabled())
+        if (outer is None and noise_is_constant and self._mat_Q_L.is_cuda
+                and max(self.z_dim, self.a_dim) <= 32):
+            # no gradient flows into the noise factors: Q, R and chol(R) in one launch
+            Q, R, L_R = F.noise_factors(self._mat_Q_L, self._mat_R_L, self.Q_reg, self.R_reg)
+            self._matrix_cache.update(Q=Q, R=R, L_R=L_R)
         try:
             yield self
         finally:
@@ -179,8 +187,13 @@ class StateSpaceModel(nn.Module):
                 raise ValueError("sample_control.observation must be 'sample' for training")
         return state, obs
 
-    @staticmethod
-    def _draw(shape, like):
+    def _draw(self, shape, like):
+        """A standard-normal tensor; served from the pre-drawn pool (one launch for all
+        the noise of a step, see kalman_elbo) when one is installed."""
+        pool = self._noise_pool
+        if pool:
+            assert tuple(pool[0].shape) == tuple(shape), (tuple(pool[0].shape), tuple(shape))
+            return pool.pop(0)
         return _standard_normal(shape, dtype=like.dtype, device=like.device)
 
     def _finish(self, device):
@@ -219,11 +232,10 @@ class StateSpaceModel(nn.Module):
                     self._draw((B, self.z_dim), as_)
                 if obs_noise:
                     self._draw((B, self.a_dim), as_)
-        later = self.weight_model(as_)  # rows 1..T: weights after seeing a_0..a_{T-1}
+        # row 0: uniform weights; rows 1..T: weights after seeing a_0..a_{T-1}
+        alpha = self.weight_model(as_, lead=True)
         if not learn_weight_model:
-            later = later.detach()
-        first = torch.full((1, B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
-        alpha = torch.cat([first, later], dim=0)
+            alpha = alpha.detach()
         m, P, mn, Pn, As, Cs = F.kalman_filter_steps(
             as_, alpha, None, self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R,
             self.initial_state_mean, self.initial_state_covariance,

@@ -123,6 +123,8 @@ int elbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
     g.f = mk<R>(d, &io->fwd);
     g.g_obs = (const R*)io->g_obs; g.g_trans = (const R*)io->g_trans;
     g.g_post = (const R*)io->g_post;
+    g.g_scale = (const R*)io->g_scale; g.g_scale_stride = io->g_scale_stride;
+    g.w_obs = (R)io->w_obs; g.w_trans = (R)io->w_trans; g.w_post = (R)io->w_post;
     g.d_a = (R*)io->d_a; g.d_ms = (R*)io->d_mean_smooth; g.d_Ps = (R*)io->d_cov_smooth;
     g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs; g.partial = nullptr;
     std::vector<R> acc(PG::LEN, R(0));
@@ -171,6 +173,8 @@ ElboBwdArgs<R> mkb(const kvae_dims* d, const kvae_elbo_bwd* io) {
     g.f = mk<R>(d, &io->fwd);
     g.g_obs = (const R*)io->g_obs; g.g_trans = (const R*)io->g_trans;
     g.g_post = (const R*)io->g_post;
+    g.g_scale = (const R*)io->g_scale; g.g_scale_stride = io->g_scale_stride;
+    g.w_obs = (R)io->w_obs; g.w_trans = (R)io->w_trans; g.w_post = (R)io->w_post;
     g.d_a = (R*)io->d_a; g.d_ms = (R*)io->d_mean_smooth; g.d_Ps = (R*)io->d_cov_smooth;
     g.d_As = (R*)io->d_mat_As; g.d_Cs = (R*)io->d_mat_Cs; g.partial = nullptr;
     return g;

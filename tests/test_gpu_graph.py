@@ -159,3 +159,57 @@ def test_fused_filter_smooth_call_equals_separate_calls(n, p, K, dtype):
     for x, y in zip(fused, tuple(filt) + tuple(smo)):
         assert torch.equal(x, y)
     assert F.read_status(dev) == 0
+
+
+@pytest.mark.parametrize("n,p,K,dtype,family", [
+    (4, 2, 3, torch.float32, None), (4, 2, 3, torch.float64, None),
+    (16, 8, 4, torch.float64, None), (32, 16, 8, torch.float32, "tile"),
+    (32, 16, 8, torch.float32, "lds")])
+def test_elbo_objective_node_equals_terms_then_weighted_sum(n, p, K, dtype, family):
+    """The fused node (terms + weighted totals, scalar cotangents in the kernel) against
+    the per-term node followed by torch arithmetic: objective, weighted totals and the
+    gradient w.r.t. every input, for one shared upstream scalar and for separate
+    cotangents of the three weighted totals."""
+    import os
+    from kalman_vae_amd import functions as F
+    if family:
+        os.environ["KVAE_LARGE_STATE"] = family
+    try:
+        torch.manual_seed(n + p)
+        dev = torch.device("cuda:0")
+        T, B = 7, 37
+        r = lambda *s: torch.randn(*s, dtype=dtype, device=dev)
+
+        def spd(*lead):
+            w = r(*lead, n, n)
+            return 0.6 * torch.eye(n, dtype=dtype, device=dev) + 0.05 * w @ w.transpose(-1, -2)
+
+        base = [r(T, B, p), r(T, B, n), spd(T, B), 0.2 * r(T + 1, B, n, n), 0.3 * r(T + 1, B, p, n),
+                spd(), 0.5 * torch.eye(p, dtype=dtype, device=dev) + 0.01, r(n), spd()]
+        base[6] = 0.5 * (base[6] + base[6].T)
+        eps = r(T, B, n)
+        w = (0.7, -1.3, 0.4)
+        tol = 2e-4 if dtype == torch.float32 else 1e-10
+
+        def grads(fused, cot):
+            ins = [t.clone().requires_grad_(True) for t in base]
+            if fused:
+                obj, weighted, _, _ = F.kalman_elbo_objective(*ins, eps, *w)
+            else:
+                obs, trans, post, _ = F.kalman_elbo_terms(*ins, eps)
+                weighted = torch.stack([w[0] * obs.sum(), w[1] * trans.sum(), w[2] * post.sum()])
+                obj = weighted.sum()
+            loss = obj * 1.7 if cot is None else obj * 1.7 + (weighted * cot).sum()
+            return obj.detach(), weighted.detach(), torch.autograd.grad(loss, ins)
+
+        for cot in (None, torch.tensor([0.3, -2.0, 1.1], dtype=dtype, device=dev)):
+            o1, w1, g1 = grads(True, cot)
+            o2, w2, g2 = grads(False, cot)
+            scale = float(w2.abs().max())
+            assert abs(float(o1) - float(o2)) < tol * scale
+            assert float((w1 - w2).abs().max()) < tol * scale
+            for a, b in zip(g1, g2):
+                assert float((a - b).abs().max()) <= tol * max(1e-30, float(b.abs().max()))
+        assert F.read_status(dev) == 0
+    finally:
+        os.environ.pop("KVAE_LARGE_STATE", None)
