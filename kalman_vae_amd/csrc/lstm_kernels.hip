@@ -362,14 +362,16 @@ __device__ __forceinline__ void cell_epilogue(const f32x16 (&acc)[4], float (&c)
         h_tile[lr * PLDA + u] = h;
         if (row < B) {
             const long o = (long)row * PH + u;
-            h_t[o] = h;
-            c_t[o] = c[r];
+            // written once, read again only by the backward pass: keep them out of
+            // the L2's way, it holds the weights every workgroup re-reads each step
+            __builtin_nontemporal_store(h, h_t + o);
+            __builtin_nontemporal_store(c[r], c_t + o);
             if (gates_t) {
                 float* gr = gates_t + (long)row * PG4 + u;
-                gr[0] = ig;
-                gr[PH] = fg;
-                gr[2 * PH] = gg;
-                gr[3 * PH] = og;
+                __builtin_nontemporal_store(ig, gr);
+                __builtin_nontemporal_store(fg, gr + PH);
+                __builtin_nontemporal_store(gg, gr + 2 * PH);
+                __builtin_nontemporal_store(og, gr + 3 * PH);
             }
         }
     }
@@ -466,6 +468,20 @@ lstm2_persistent_forward_kernel(int T, int B, const float* __restrict__ x,      
 // so weight loads, h/c/gate stores and LDS writes are all 8-byte accesses.
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Streaming accesses for tensors that pass through once (activations saved for the
+// backward pass, gate gradients): keeping them out of the L2's way leaves it to the
+// weights every workgroup re-reads each step.
+__device__ __forceinline__ void store_streaming(float* p, float2 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+}
+__device__ __forceinline__ float2 load_streaming(const float* p) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return make_float2(w[0], w[1]);
+}
+
 constexpr int PLDA16 = PH + 4;     // LDS row stride of a 16-row h tile
 constexpr int LDG16 = PG4 + 4;     // LDS row stride of a 16-row gate-gradient tile
 constexpr int KC16 = 4;            // k-steps (of 4) per prefetch chunk, forward
@@ -499,14 +515,22 @@ struct WChunk4 {
     }
 };
 
+// b0 arrives holding the first chunk of Bt (preload16): a product that follows a cell
+// epilogue gets its first weights requested BEFORE the epilogue's stores, because loads
+// and stores share one in-order counter and a load queued behind ~20 KB of stores per
+// wavefront waits for all of them to drain.
+__device__ __forceinline__ const float* weight_base16(const float* __restrict__ Bt, int u0) {
+    const int lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
+    return Bt + u0 + 2 * c + (long)s * PG4;
+}
 __device__ __forceinline__ void mfma16_k128_4gates(f32x4 (&acc)[4][2], const float* a_tile,
-                                                   const float* __restrict__ Bt, int u0) {
+                                                   const float* __restrict__ Bt, int u0,
+                                                   WChunk4& b0) {
     static_assert((PH / 4) % (2 * KC16) == 0, "chunk pairs must tile K");
     const int lane = threadIdx.x & 63, c = lane & 15, s = lane >> 4;
-    const float* wb = Bt + u0 + 2 * c + (long)s * PG4;
+    const float* wb = weight_base16(Bt, u0);
     const float* a_row = a_tile + c * PLDA16 + s;
-    WChunk4 b0, b1;
-    b0.load(wb, 0);
+    WChunk4 b1;
 #pragma unroll 1
     for (int kk0 = 0; kk0 < PH / 4; kk0 += 2 * KC16) {
         b1.load(wb, kk0 + KC16);
@@ -514,6 +538,12 @@ __device__ __forceinline__ void mfma16_k128_4gates(f32x4 (&acc)[4][2], const flo
         if (kk0 + 2 * KC16 < PH / 4) b0.load(wb, kk0 + 2 * KC16);
         b1.apply(acc, a_row, kk0 + KC16);
     }
+}
+__device__ __forceinline__ void mfma16_k128_4gates(f32x4 (&acc)[4][2], const float* a_tile,
+                                                   const float* __restrict__ Bt, int u0) {
+    WChunk4 b0;
+    b0.load(weight_base16(Bt, u0), 0);
+    mfma16_k128_4gates(acc, a_tile, Bt, u0, b0);
 }
 
 __device__ __forceinline__ void cell_epilogue16(const f32x4 (&acc)[4][2], float (&cst)[4][2], int B,
@@ -535,14 +565,14 @@ __device__ __forceinline__ void cell_epilogue16(const f32x4 (&acc)[4][2], float 
         *reinterpret_cast<float2*>(h_tile + lr * PLDA16 + ub) = hv;
         if (row < B) {
             const long o = (long)row * PH + ub;
-            *reinterpret_cast<float2*>(h_t + o) = hv;
-            *reinterpret_cast<float2*>(c_t + o) = cv;
+            store_streaming(h_t + o, hv);
+            store_streaming(c_t + o, cv);
             if (gates_t) {
                 float* gr = gates_t + (long)row * PG4 + ub;
-                *reinterpret_cast<float2*>(gr) = ig;
-                *reinterpret_cast<float2*>(gr + PH) = fg;
-                *reinterpret_cast<float2*>(gr + 2 * PH) = gg;
-                *reinterpret_cast<float2*>(gr + 3 * PH) = og;
+                store_streaming(gr, ig);
+                store_streaming(gr + PH, fg);
+                store_streaming(gr + 2 * PH, gg);
+                store_streaming(gr + 3 * PH, og);
             }
         }
     }
@@ -600,6 +630,8 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
             for (int q = 0; q < P; ++q) wx[g][hf][q] = Wih0[(long)(g * PH + ub + hf) * P + q];
         }
     }
+    WChunk4 pre;
+    pre.load(weight_base16(Whh0T, u0), 0);
     for (int t = 0; t < T; ++t) {
         f32x4 acc[4][2];
 #pragma unroll
@@ -619,7 +651,8 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
                 }
             }
         }
-        if (t > 0 || carried) mfma16_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0);
+        if (t > 0 || carried) mfma16_k128_4gates(acc, hbuf0[(t - 1) & 1], Whh0T, u0, pre);
+        pre.load(weight_base16(Wih1T, u0), 0);      // ahead of the epilogue's stores
         cell_epilogue16(acc, c0, B, r0, ub, s, gates0 ? gates0 + t * BG : nullptr, h0 + t * BH, c0g + t * BH,
                         hbuf0[t & 1]);
         __syncthreads();
@@ -631,8 +664,9 @@ lstm2_persistent_forward16_kernel(int T, int B, const float* __restrict__ x,
                 for (int i = 0; i < 4; ++i) acc[g][hf][i] = bias1[g][hf];
             }
         }
-        mfma16_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0);
+        mfma16_k128_4gates(acc, hbuf0[t & 1], Wih1T, u0, pre);
         if (t > 0 || carried) mfma16_k128_4gates(acc, hbuf1[(t - 1) & 1], Whh1T, u0);
+        pre.load(weight_base16(Whh0T, u0), 0);      // for the next step, ahead of the stores
         cell_epilogue16(acc, c1, B, r0, ub, s, gates1 ? gates1 + t * BG : nullptr, h1 + t * BH, c1g + t * BH,
                         hbuf1[t & 1]);
         // the barrier of step t+1 orders these h1 writes before their first read,
@@ -736,13 +770,13 @@ struct CellIn {
             ig[i] = fg[i] = gg[i] = og[i] = cc[i] = cp[i] = z;
             if (row < B) {
                 const float* gr = gates + t * BG + (long)row * PG4 + ub;
-                ig[i] = *reinterpret_cast<const float2*>(gr);
-                fg[i] = *reinterpret_cast<const float2*>(gr + PH);
-                gg[i] = *reinterpret_cast<const float2*>(gr + 2 * PH);
-                og[i] = *reinterpret_cast<const float2*>(gr + 3 * PH);
+                ig[i] = load_streaming(gr);
+                fg[i] = load_streaming(gr + PH);
+                gg[i] = load_streaming(gr + 2 * PH);
+                og[i] = load_streaming(gr + 3 * PH);
                 const long o = (long)row * PH + ub;
-                cc[i] = *reinterpret_cast<const float2*>(cg + t * BH + o);
-                if (t > 0) cp[i] = *reinterpret_cast<const float2*>(cg + (t - 1) * BH + o);
+                cc[i] = load_streaming(cg + t * BH + o);
+                if (t > 0) cp[i] = load_streaming(cg + (t - 1) * BH + o);
             }
         }
     }
@@ -780,10 +814,10 @@ __device__ __forceinline__ void cell_backward16(const float (&dh)[4][2], float (
         }
         if (row < B) {
             float* d = dG + t * BG + (long)row * PG4 + ub;
-            *reinterpret_cast<float2*>(d) = di;
-            *reinterpret_cast<float2*>(d + PH) = df;
-            *reinterpret_cast<float2*>(d + 2 * PH) = dg;
-            *reinterpret_cast<float2*>(d + 3 * PH) = dout;
+            store_streaming(d, di);
+            store_streaming(d + PH, df);
+            store_streaming(d + 2 * PH, dg);
+            store_streaming(d + 3 * PH, dout);
         }
         float* tl = g_tile + lr * LDG16 + ub;
         *reinterpret_cast<float2*>(tl) = di;
