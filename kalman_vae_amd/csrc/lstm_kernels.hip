@@ -1010,7 +1010,11 @@ inline bool lstm2_use_16_row_tiles(int B) {
     const int forced = e ? atoi(e) : 0;
     if (forced == 16) return true;
     if (forced == 32) return false;
-    return (B + 31) / 32 < 256;
+    // 32-row tiles stream the weights half as often but halve the workgroup count; they
+    // win only where the 16-row grid would need a second pass over the 256 CUs and
+    // the 32-row grid does not (measured: 4096 < B <= 8192)
+    const int tiles16 = (B + 15) / 16;
+    return !(tiles16 > 256 && tiles16 <= 512);
 }
 
 // Operands of the persistent forward kernel from the module's parameters in one
