@@ -94,6 +94,68 @@ def kernel_bytes(n, p, K, el):
     }
 
 
+MFMA_FP32_PEAK_TF = 157.3   # dense fp32 matrix-core peak of MI355X
+
+
+def time_lstm_kernels(ssm, a, iters=20):
+    """HIP-event durations of the two persistent LSTM kernels of the weight network
+    (the step's longest kernels) at the bench shape, launched through the C ABI on
+    the current stream; None when the network is not the default two-layer H=128 LSTM."""
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd import lstm_function as LF
+    net = ssm.weight_model
+    lstm = getattr(net, "lstm", None)
+    if lstm is None or not LF.persistent_supported(a, lstm):
+        return None
+    lib = capi.load()
+    T, B, P = a.shape
+    H = 128
+    dev = a.device
+    x = a.detach().contiguous()
+    w = lambda nme: getattr(lstm, nme).detach()
+    whh0t, wih1t, whh1t, b0, b1 = LF._lstm2_operands(
+        w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
+        w("bias_ih_l1"), w("bias_hh_l1"))
+    new = lambda *s: torch.empty(*s, dtype=x.dtype, device=dev)
+    g0, h0, c0, g1, h1, c1 = (new(T, B, 4 * H), new(T, B, H), new(T, B, H), new(T, B, 4 * H),
+                              new(T, B, H), new(T, B, H))
+    dG0, dG1, dx = torch.empty_like(g0), torch.empty_like(g1), torch.empty_like(x)
+    gh = torch.randn(T, B, H, dtype=x.dtype, device=dev) * 1e-3
+    part = new(lib.kvae_lstm2_backward_blocks(B), 4 * H * (2 + P))
+    wih0 = w("weight_ih_l0").contiguous()
+    st = capi.current_stream_ptr()
+
+    def fwd():
+        capi.check(lib.kvae_lstm2_forward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
+            wih1t.data_ptr(), whh1t.data_ptr(), b1.data_ptr(), g0.data_ptr(), h0.data_ptr(),
+            c0.data_ptr(), g1.data_ptr(), h1.data_ptr(), c1.data_ptr(), None, None, st))
+
+    def bwd():
+        capi.check(lib.kvae_lstm2_backward(
+            T, B, P, gh.data_ptr(), x.data_ptr(), g0.data_ptr(), c0.data_ptr(), g1.data_ptr(),
+            c1.data_ptr(), wih0.data_ptr(), w("weight_hh_l0").contiguous().data_ptr(),
+            w("weight_ih_l1").contiguous().data_ptr(), w("weight_hh_l1").contiguous().data_ptr(),
+            dG0.data_ptr(), dG1.data_ptr(), dx.data_ptr(), part.data_ptr(), st))
+
+    flops = 2.0 * T * B * 4 * H * 3 * H     # one recurrent product per layer + layer 1's input product
+    out = {}
+    for name, fn in (("lstm_forward", fwd), ("lstm_backward", bwd)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) / iters * 1e-3
+        out[name] = {"us": sec * 1e6, "bound": "mfma", "achieved": flops / sec / 1e12,
+                     "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / sec / 1e12 / MFMA_FP32_PEAK_TF, "flops_per_launch": flops}
+    return out
+
+
 def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
     """Average duration of each HIP kernel of the step, measured with HIP events on
     the stream the kernels are launched on, by replaying each launch `iters` times
@@ -380,6 +442,12 @@ def main():
                 "valu_frac": kflops[dom] * units / kt[dom] / 1e12 / VALU_FP32_PEAK_TF,
             }
             total_k = sum(kt.values())
+            if not args.kernels_only:
+                # the weight network's recurrence: the longest kernels of the whole step,
+                # bound by the fp32 matrix core rather than by HBM
+                lk = time_lstm_kernels(ssm, a)
+                if lk is not None:
+                    result["weight_network_kernels"] = lk
             result["kernels"] = kernels
             result["kernel_only"] = {
                 "us_per_step": total_k * 1e6,
