@@ -4,7 +4,9 @@
 // translation unit (wave_kernels.hip) tries these first and falls back to its
 // LDS-resident kernels for other shapes and for fp64; KVAE_LARGE_STATE=lds in
 // the environment forces the LDS kernels (used by the tests to compare the two).
+#include <cstdint>
 #include <cstdlib>
+#include <initializer_list>
 #include <cstring>
 
 #include "kalman_tile.h"
@@ -56,6 +58,13 @@ __global__ void __launch_bounds__(64) tile_filter_backward_kernel(FilterBwdArgs<
     X(32, 16)                 \
     X(16, 8)
 
+// the tile kernels read and write matrix rows 16 bytes at a time
+static bool aligned16(std::initializer_list<const void*> ptrs) {
+    for (const void* p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return true;
+}
+
 bool tile_enabled() {
     const char* e = std::getenv("KVAE_LARGE_STATE");
     return !(e && std::strcmp(e, "lds") == 0);
@@ -73,6 +82,7 @@ int tile_supported(int n, int p, int dtype) {
 int tile_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
     if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
     FilterFwdArgs<float> g = make_args<float>(d, io);
+    if (!aligned16({g.A_K, g.C_K, g.As, g.Cs})) return KVAE_E_UNSUPPORTED;
 #define KVAE_CASE(n_, p_)                                                                        \
     if (d->n == n_ && d->p == p_) {                                                              \
         hipLaunchKernelGGL((tile_filter_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g,   \
@@ -87,7 +97,9 @@ int tile_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream
 // the per-sequence recursion of the filter backward only; the caller runs the
 // reductions and the mixing-adjoint passes over bar_As / bar_Cs
 int tile_filter_backward_main(const kvae_dims* d, const FilterBwdArgs<float>& g, hipStream_t s) {
-    if (!tile_supported(d->n, d->p, d->dtype) || !g.f.As || !g.f.Cs) return KVAE_E_UNSUPPORTED;
+    if (!tile_supported(d->n, d->p, d->dtype) || !g.f.As || !g.f.Cs ||
+        !aligned16({g.f.As, g.f.Cs}))
+        return KVAE_E_UNSUPPORTED;
 #define KVAE_CASE(n_, p_)                                                                        \
     if (d->n == n_ && d->p == p_) {                                                              \
         hipLaunchKernelGGL((tile_filter_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g); \
@@ -101,6 +113,7 @@ int tile_filter_backward_main(const kvae_dims* d, const FilterBwdArgs<float>& g,
 int tile_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
     if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
     SmoothFwdArgs<float> g = make_args<float>(d, io);
+    if (!aligned16({g.As, g.Cs, g.LR})) return KVAE_E_UNSUPPORTED;
 #define KVAE_CASE(n_, p_)                                                                        \
     if (d->n == n_ && d->p == p_) {                                                              \
         hipLaunchKernelGGL((tile_smooth_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
@@ -118,6 +131,7 @@ int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws
     if (d->n == n_ && d->p == p_) {                                                               \
         if (io->d_LR && ws_bytes < (size_t)d->B * p_ * p_ * sizeof(float)) return KVAE_E_WORKSPACE; \
         SmoothBwdArgs<float> g = make_args<float>(d, io, ws);                                     \
+        if (!aligned16({g.f.As, g.f.Cs, g.f.LR})) return KVAE_E_UNSUPPORTED;                      \
         hipLaunchKernelGGL((tile_smooth_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
         if (io->d_LR) reduce_smooth_grads<float, p_>(io, ws, d->B, s);                            \
         return launch_status();                                                                   \
@@ -130,6 +144,7 @@ int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws
 int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
     if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
     ElboFwdArgs<float> g = make_args<float>(d, io);
+    if (!aligned16({g.As, g.Cs})) return KVAE_E_UNSUPPORTED;
 #define KVAE_CASE(n_, p_)                                                                       \
     if (d->n == n_ && d->p == p_) {                                                             \
         hipLaunchKernelGGL((tile_elbo_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);   \
@@ -148,6 +163,7 @@ int tile_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, si
         using PG = ElboParamGrads<n_, p_>;                                                       \
         if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(float)) return KVAE_E_WORKSPACE;          \
         ElboBwdArgs<float> g = make_args<float>(d, io, ws);                                      \
+        if (!aligned16({g.f.As, g.f.Cs})) return KVAE_E_UNSUPPORTED;                             \
         hipLaunchKernelGGL((tile_elbo_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
         reduce_elbo_grads<float, n_, p_>(io, ws, d->B, s);                                       \
         return launch_status();                                                                  \

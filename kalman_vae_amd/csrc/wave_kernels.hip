@@ -291,7 +291,10 @@ size_t wave_workspace_bytes(const kvae_dims* d, int op) {
 }
 
 int wave_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io, hipStream_t s) {
-    if (tile_supported(d->n, d->p, d->dtype)) return tile_filter_forward(d, io, s);
+    if (tile_supported(d->n, d->p, d->dtype)) {   // e.g. refuses unaligned operands
+        const int rc = tile_filter_forward(d, io, s);
+        if (rc != KVAE_E_UNSUPPORTED) return rc;
+    }
 #define KVAE_CALL(R, n_, p_, K_) run_wave_filter_forward<R, n_, p_, K_>(d, io, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
@@ -305,7 +308,10 @@ int wave_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* ws
     return KVAE_E_UNSUPPORTED;
 }
 int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream_t s) {
-    if (tile_supported(d->n, d->p, d->dtype)) return tile_smooth_forward(d, io, s);
+    if (tile_supported(d->n, d->p, d->dtype)) {   // e.g. refuses unaligned operands
+        const int rc = tile_smooth_forward(d, io, s);
+        if (rc != KVAE_E_UNSUPPORTED) return rc;
+    }
 #define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_forward<R, n_, p_>(d, io, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
@@ -313,14 +319,20 @@ int wave_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream
 }
 int wave_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
                          hipStream_t s) {
-    if (tile_supported(d->n, d->p, d->dtype)) return tile_smooth_backward(d, io, ws, ws_bytes, s);
+    if (tile_supported(d->n, d->p, d->dtype)) {   // e.g. refuses unaligned operands
+        const int rc = tile_smooth_backward(d, io, ws, ws_bytes, s);
+        if (rc != KVAE_E_UNSUPPORTED) return rc;
+    }
 #define KVAE_CALL(R, n_, p_, K_) run_wave_smooth_backward<R, n_, p_>(d, io, ws, ws_bytes, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
     return KVAE_E_UNSUPPORTED;
 }
 int wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
-    if (tile_supported(d->n, d->p, d->dtype)) return tile_elbo_forward(d, io, s);
+    if (tile_supported(d->n, d->p, d->dtype)) {   // e.g. refuses unaligned operands
+        const int rc = tile_elbo_forward(d, io, s);
+        if (rc != KVAE_E_UNSUPPORTED) return rc;
+    }
 #define KVAE_CALL(R, n_, p_, K_) run_wave_elbo_forward<R, n_, p_>(d, io, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL
@@ -328,7 +340,10 @@ int wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s
 }
 int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
                        hipStream_t s) {
-    if (tile_supported(d->n, d->p, d->dtype)) return tile_elbo_backward(d, io, ws, ws_bytes, s);
+    if (tile_supported(d->n, d->p, d->dtype)) {   // e.g. refuses unaligned operands
+        const int rc = tile_elbo_backward(d, io, ws, ws_bytes, s);
+        if (rc != KVAE_E_UNSUPPORTED) return rc;
+    }
 #define KVAE_CALL(R, n_, p_, K_) run_wave_elbo_backward<R, n_, p_>(d, io, ws, ws_bytes, s)
     KVAE_WAVE_DIM_LIST(KVAE_WAVE_CASE)
 #undef KVAE_CALL

@@ -213,3 +213,34 @@ def test_elbo_objective_node_equals_terms_then_weighted_sum(n, p, K, dtype, fami
         assert F.read_status(dev) == 0
     finally:
         os.environ.pop("KVAE_LARGE_STATE", None)
+
+
+def test_large_state_kernels_accept_unaligned_operands():
+    """The register-tile kernels move matrix rows 16 bytes at a time; operands that are
+    not 16-byte aligned (a view one float into a buffer) take the LDS kernels instead
+    and give the same result."""
+    from kalman_vae_amd import functions as F
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    T, B, n, p = 5, 3, 32, 16
+    r = lambda *s: torch.randn(*s, device=dev)
+
+    def spd(*lead):
+        w = r(*lead, n, n)
+        return 0.6 * torch.eye(n, device=dev) + 0.03 * w @ w.transpose(-1, -2)
+
+    def shifted(t):     # same values, storage offset of one float
+        buf = torch.empty(t.numel() + 1, device=dev)
+        buf[1:] = t.reshape(-1)
+        return buf[1:].view(t.shape)
+
+    a, ms, Ps = r(T, B, p), r(T, B, n), spd(T, B)
+    As, Cs = 0.2 * r(T + 1, B, n, n), 0.3 * r(T + 1, B, p, n)
+    Q, R, m0, P0, eps = spd(), 0.5 * torch.eye(p, device=dev), r(n), spd(), r(T, B, n)
+    want = F.kalman_elbo_terms(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+    As2, Cs2 = shifted(As), shifted(Cs)
+    assert As2.data_ptr() % 16 != 0 and As2.is_contiguous()
+    got = F.kalman_elbo_terms(a, ms, Ps, As2, Cs2, Q, R, m0, P0, eps)
+    for x, y in zip(got[:3], want[:3]):
+        assert float((x - y).abs().max()) < 1e-4 * float(y.abs().max())
+    assert F.read_status(dev) == 0
