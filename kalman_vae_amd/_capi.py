@@ -204,6 +204,20 @@ def column_sum(x):
     return out
 
 
+def column_sum_tall(x):
+    """Column sums of a contiguous (rows, cols) GPU tensor with many rows and few
+    columns: kvae_column_sum gives every 64 columns one workgroup, so k consecutive
+    rows are first viewed as one row of k*cols columns (k workgroup groups share the
+    rows), then the k partial sums per column are added by a second call."""
+    rows, cols = x.shape
+    k = 1
+    while k < 256 and rows % (2 * k) == 0 and rows // (2 * k) >= 64:
+        k *= 2
+    if k == 1:
+        return column_sum(x)
+    return column_sum(column_sum(x.view(rows // k, k * cols)).view(k, cols))
+
+
 def check(code):
     if code != 0:
         raise RuntimeError("kvae kernel call failed: "

@@ -104,7 +104,7 @@ class MLPModel(nn.Module):
         for i, layer in enumerate(self.layers):
             if i == last:
                 return lstm_function.softmax_head(x, layer, lead)
-            x = torch.relu(layer(x))
+            x = torch.relu(lstm_function.linear(x, layer))
 
     is_recurrent = False
 

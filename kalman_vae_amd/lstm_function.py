@@ -227,6 +227,46 @@ class SoftmaxHeadFunction(torch.autograd.Function):
         return d_h.view(*ctx.lead, H), sums[:K * H].view(K, H), sums[K * H:], None
 
 
+class LinearFunction(torch.autograd.Function):
+    """x (..., I) @ W^T + b with the bias gradient summed by the package's
+    deterministic column sum.  torch.nn.Linear's own bias gradient is a many-row
+    reduction whose kernel zeroes a semaphore with a memset node, which keeps a step
+    that contains it from being replayed as a HIP graph on this ROCm version."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.nn.functional.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        d_x = (g2 @ W).view(x.shape) if ctx.needs_input_grad[0] else None
+        d_W = None
+        if ctx.needs_input_grad[1]:
+            if x2.shape[1] <= 8:
+                # a few input features (the network's first layer sees a_dim of them): a
+                # GEMM with so narrow an operand is badly shaped, one scaled column sum
+                # per feature is not
+                g2c = g2.contiguous()
+                d_W = torch.stack([capi.column_sum_tall(g2c * x2[:, q:q + 1])
+                                   for q in range(x2.shape[1])], dim=1)
+            else:
+                d_W = _splitk_tn(g2, x2)
+        d_b = capi.column_sum_tall(g2.contiguous()) if ctx.needs_input_grad[2] else None
+        return d_x, d_W, d_b
+
+
+def linear(x, layer):
+    """layer(x) for a torch.nn.Linear; on a GPU in float32/float64 with a bias the
+    gradient path avoids library reductions (see LinearFunction)."""
+    if x.is_cuda and layer.bias is not None and x.dtype in (torch.float32, torch.float64):
+        return LinearFunction.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 def head_supported(h, linear):
     return (h.is_cuda and h.dtype == torch.float32 and linear.in_features in (32, 64, 128, 256)
             and linear.out_features <= 8 and linear.bias is not None)

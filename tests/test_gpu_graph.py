@@ -244,3 +244,30 @@ def test_large_state_kernels_accept_unaligned_operands():
     for x, y in zip(got[:3], want[:3]):
         assert float((x - y).abs().max()) < 1e-4 * float(y.abs().max())
     assert F.read_status(dev) == 0
+
+
+@pytest.mark.parametrize("rows,cols", [(81920, 128), (4096 * 19, 2), (1000, 7), (63, 128)])
+def test_column_sum_of_tall_matrices(rows, cols):
+    from kalman_vae_amd import _capi as capi
+    torch.manual_seed(rows)
+    x = torch.randn(rows, cols, device="cuda:0")
+    got = capi.column_sum_tall(x)
+    want = x.double().sum(0)
+    assert float((got.double() - want).abs().max()) < 1e-5 * float(x.double().abs().sum(0).max())
+
+
+def test_mlp_linear_layer_matches_torch_linear():
+    """The MLP network's hidden layers run through a Linear whose bias gradient uses the
+    package's column sum (no memset node): same values and gradients as torch.nn.Linear."""
+    from kalman_vae_amd.lstm_function import linear
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    for fan_in in (2, 128):
+        layer = torch.nn.Linear(fan_in, 128).to(dev)
+        x1 = torch.randn(20, 512, fan_in, device=dev, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        cot = torch.randn(20, 512, 128, device=dev)
+        g1 = torch.autograd.grad((linear(x1, layer) * cot).sum(), [x1, layer.weight, layer.bias])
+        g2 = torch.autograd.grad((layer(x2) * cot).sum(), [x2, layer.weight, layer.bias])
+        for a, b in zip(g1, g2):
+            assert rel_err(a, b) < 1e-5
