@@ -302,7 +302,14 @@ def lstm2_nograd(x, lstm, hidden=None):
     H = 128
     x = x.contiguous()
     new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
-    h0, c0, h1, c1 = new(T, B, H), new(T, B, H), new(T, B, H), new(T, B, H)
+    if T == 1:
+        # one step: the kernel writes the two layers' h and c straight into the
+        # (2,B,H) state tensors the next call starts from (no stacking copies)
+        h_n, c_n = new(2, B, H), new(2, B, H)
+        h0, h1, c0, c1 = h_n[0:1], h_n[1:2], c_n[0:1], c_n[1:2]
+    else:
+        h_n = c_n = None
+        h0, c0, h1, c1 = new(T, B, H), new(T, B, H), new(T, B, H), new(T, B, H)
     w = lambda n: getattr(lstm, n)
     whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(
         w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
@@ -315,6 +322,8 @@ def lstm2_nograd(x, lstm, hidden=None):
         T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), None, h0.data_ptr(), c0.data_ptr(),
         None, h1.data_ptr(), c1.data_ptr(), capi.ptr(h_init), capi.ptr(c_init),
         capi.current_stream_ptr()))
+    if T == 1:
+        return h1, (h_n, c_n)
     return h1, (torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]]))
 
 
