@@ -200,6 +200,18 @@ typedef struct {
 int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* One step of the masked filter's imputation, kvae/state_space_model.py:232-277, for
+ * every sequence: z = A(w) m_pred (+ L_Q eps_z), a_imp = C(w) z (+ L_R eps_a),
+ * a_w = mask * a + (1 - mask) * a_imp, with A(w) = sum_k w[b,k] A_K[k] (C alike).
+ * Uses B, n, p, K, dtype of d.  w (B,K), m_pred (B,n), a (B,p), mask (B), eps_z (B,n) /
+ * eps_a (B,p) standard-normal draws or NULL ("mean" mode), L_Q (n,n) / L_R (p,p) lower
+ * Cholesky factors (needed with the draws), a_w (B,p) output: the observation the weight
+ * network sees next.  Small state dimensions only (KVAE_E_UNSUPPORTED otherwise). */
+int kvae_impute_observation(const kvae_dims *d, const void *w, const void *A_K, const void *C_K,
+                            const void *m_pred, const void *a, const void *mask,
+                            const void *eps_z, const void *L_Q, const void *eps_a,
+                            const void *L_R, void *a_w, void *stream);
+
 /* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
  * (and of the imputation path kvae/evaluation.py:100-140): runs
  * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream`.

@@ -65,7 +65,7 @@ EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
     "kvae_filter_forward", "kvae_filter_backward",
     "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
-    "kvae_elbo_forward", "kvae_elbo_backward",
+    "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
@@ -166,6 +166,8 @@ def load():
     lib.kvae_softmax_head_backward.restype = C.c_int
     lib.kvae_softmax_head_backward_blocks.argtypes = [C.c_long]
     lib.kvae_softmax_head_backward_blocks.restype = C.c_int
+    lib.kvae_impute_observation.argtypes = [C.POINTER(Dims)] + [_vp] * 12
+    lib.kvae_impute_observation.restype = C.c_int
     lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
     lib.kvae_lstm2_prepare.restype = C.c_int
     lib.kvae_lstm2_prepared_elems.argtypes = []

@@ -273,6 +273,69 @@ using namespace kvae;
 
 // Expands `CALL(R, n, p, K)` for the compiled combination matching d, else
 // returns KVAE_E_UNSUPPORTED.
+// The imputation the masked filter does before each call of the weight network
+// (kvae/state_space_model.py:232-277), one lane per sequence:
+//   z = A(w) m_pred (+ L_Q eps_z),  a_imp = C(w) z (+ L_R eps_a),  a_w = mu a + (1 - mu) a_imp
+// with A(w), C(w) the K-way mixtures for this sequence's weights w.  As separate library
+// calls this is ~15 launches per step.
+template <typename R>
+struct ImputeArgs {
+    long B;
+    const R *w, *A_K, *C_K, *m_pred, *a, *mask, *eps_z, *L_Q, *eps_a, *L_R;
+    R* a_w;
+};
+
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(SEQ_BLOCK) impute_kernel(ImputeArgs<R> g) {
+    const long b = (long)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (b >= g.B) return;
+    R w[K], m[N], z[N];
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = g.w[b * K + k];
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[j] = g.m_pred[b * N + j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        R acc = R(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            R row = R(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) row += g.A_K[(k * N + i) * N + j] * m[j];
+            acc += w[k] * row;
+        }
+        if (g.eps_z) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += g.L_Q[i * N + j] * g.eps_z[b * N + j];
+        }
+        z[i] = acc;
+    }
+    const R mu = g.mask[b];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        R acc = R(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            R row = R(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) row += g.C_K[(k * P + r) * N + i] * z[i];
+            acc += w[k] * row;
+        }
+        if (g.eps_a) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) acc += g.L_R[r * P + j] * g.eps_a[b * P + j];
+        }
+        g.a_w[b * P + r] = mu * g.a[b * P + r] + (R(1) - mu) * acc;
+    }
+}
+
+template <typename R, int N, int P, int K>
+int run_impute(const ImputeArgs<R>& g, hipStream_t s) {
+    hipLaunchKernelGGL((impute_kernel<R, N, P, K>), dim3((unsigned)seq_blocks(g.B)), dim3(SEQ_BLOCK),
+                       0, s, g);
+    return launch_status();
+}
+
 #define KVAE_DISPATCH_CASE(n_, p_, K_)                                  \
     if (d->n == n_ && d->p == p_ && d->K == K_) {                       \
         if (d->dtype == KVAE_F32) return KVAE_CALL(float, n_, p_, K_);  \
@@ -415,6 +478,24 @@ int kvae_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* worksp
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
     return wave_elbo_backward(d, io, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kvae_impute_observation(const kvae_dims* d, const void* w, const void* A_K, const void* C_K,
+                            const void* m_pred, const void* a, const void* mask, const void* eps_z,
+                            const void* L_Q, const void* eps_a, const void* L_R, void* a_w,
+                            void* stream) {
+    if (!dims_ok(d) || !w || !A_K || !C_K || !m_pred || !a || !mask || !a_w || (eps_z && !L_Q) ||
+        (eps_a && !L_R))
+        return KVAE_E_BADARG;
+#define KVAE_IMPUTE(R)                                                                         \
+    ImputeArgs<R> g{d->B,          (const R*)w,     (const R*)A_K,  (const R*)C_K,             \
+                    (const R*)m_pred, (const R*)a,  (const R*)mask, (const R*)eps_z,           \
+                    (const R*)L_Q, (const R*)eps_a, (const R*)L_R,  (R*)a_w}
+#define KVAE_CALL(R, n_, p_, K_) [&] { KVAE_IMPUTE(R); return run_impute<R, n_, p_, K_>(g, (hipStream_t)stream); }()
+    KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
+#undef KVAE_CALL
+#undef KVAE_IMPUTE
+    return KVAE_E_UNSUPPORTED;
 }
 
 }  // extern "C"

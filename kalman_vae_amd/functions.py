@@ -413,6 +413,42 @@ class KalmanElboObjectiveFunction(torch.autograd.Function):
         return d_a, d_ms, d_Ps, d_As, d_Cs, d_Q, d_R, d_m0, d_P0, None, None, None, None
 
 
+@torch.no_grad()
+def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a=None, L_R=None):
+    """One step of the masked filter's imputation for every sequence in one launch
+    (kvae/state_space_model.py:232-277): returns a_w (B,p) = mask a + (1 - mask) C(w) z,
+    z = A(w) m_pred (+ L_Q eps_z) (+ L_R eps_a on the observation), or None when no
+    kernel is compiled for these dimensions (the caller then uses torch operations).
+    Values only: the step-by-step filter calls it when no gradient is recorded."""
+    capi.require_gpu(w, A_K, C_K, m_pred, a, mask)
+    B, K = w.shape
+    n, p = m_pred.shape[1], a.shape[1]
+    code = capi.dtype_code(a.dtype)
+    dims = capi.Dims(1, B, n, p, K, code, 1, 0)
+    tensors = [_c(t) for t in (w, A_K, C_K, m_pred, a, mask, eps_z, L_Q, eps_a, L_R)]
+    a_w = torch.empty(B, p, dtype=a.dtype, device=a.device)
+    rc = capi.load().kvae_impute_observation(C.byref(dims), *(capi.ptr(t) for t in tensors),
+                                             a_w.data_ptr(), capi.current_stream_ptr())
+    if rc == -2:      # KVAE_E_UNSUPPORTED
+        return None
+    capi.check(rc)
+    return a_w
+
+
+_impute_kernel_exists = {}
+
+
+def impute_supported(n, p, K, dtype, device):
+    """Whether kvae_impute_observation has a kernel for these dimensions (probed once
+    with a one-sequence call)."""
+    key = (n, p, K, dtype)
+    if key not in _impute_kernel_exists:
+        z = lambda *s: torch.zeros(*s, dtype=dtype, device=device)
+        _impute_kernel_exists[key] = impute_observation(
+            z(1, K), z(K, n, n), z(K, p, n), z(1, n), z(1, p), z(1)) is not None
+    return _impute_kernel_exists[key]
+
+
 def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,
                         want_mats=True):
     return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,

@@ -263,6 +263,12 @@ class StateSpaceModel(nn.Module):
         w = torch.full((B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
         m_pred = self.initial_state_mean.expand(B, -1).contiguous()
         P_pred = self.initial_state_covariance.expand(B, -1, -1).contiguous()
+        if (not torch.is_grad_enabled() and as_.is_cuda
+                and F.impute_supported(self.z_dim, self.a_dim, self.K, as_.dtype, as_.device)):
+            fast = self._filter_masked_inference(as_, mask, state_noise, obs_noise, symmetrize,
+                                                 w, m_pred, P_pred, L_Q, L_R)
+            if fast is not None:
+                return fast
         A_t = mix(w, A_K)
         out = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C", "aw", "w")}
         for t in range(T):
@@ -291,6 +297,37 @@ class StateSpaceModel(nn.Module):
             w, A_t = w_next, A_next
         out["A"].append(A_t)
         out["C"].append(mix(w, C_K))
+        st = {k: torch.stack(v) for k, v in out.items()}
+        return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
+
+    def _filter_masked_inference(self, as_, mask, state_noise, obs_noise, symmetrize, w, m_pred,
+                                 P_pred, L_Q, L_R):
+        """The masked filter when no gradient is recorded (the reference's imputation /
+        evaluation use): per step ONE launch imputes the observation the weight network
+        sees, the network steps from its carried state, and the one-step filter kernel
+        also writes the mixed A_t / C_t it used.  None when the imputation kernel is not
+        compiled for these dimensions."""
+        T, B = as_.shape[:2]
+        A_K, C_K, Q, R = self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R
+        out = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C", "aw", "w")}
+        As2 = Cs2 = None
+        for t in range(T):
+            eps_z = self._draw((B, self.z_dim), as_) if state_noise else None
+            eps_a = self._draw((B, self.a_dim), as_) if obs_noise else None
+            a_w = F.impute_observation(w, A_K, C_K, m_pred, as_[t], mask[t], eps_z, L_Q, eps_a, L_R)
+            if a_w is None:
+                return None
+            w_next = self.weight_model(a_w.unsqueeze(0)).squeeze(0)
+            m, P, mn, Pn, As2, Cs2 = F.kalman_filter_steps(
+                as_[t:t + 1], torch.stack([w, w_next]), mask[t:t + 1], A_K, C_K, Q, R,
+                m_pred, P_pred, symmetrize=symmetrize, burn_in=0, want_mats=True)
+            m_pred, P_pred = mn[0], Pn[0]
+            for k, v in zip(("m", "P", "mn", "Pn", "A", "C", "aw", "w"),
+                            (m[0], P[0], m_pred, P_pred, As2[0], Cs2[0], a_w, w)):
+                out[k].append(v)
+            w = w_next
+        out["A"].append(As2[1])
+        out["C"].append(Cs2[1])
         st = {k: torch.stack(v) for k, v in out.items()}
         return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
 

@@ -271,3 +271,44 @@ def test_mlp_linear_layer_matches_torch_linear():
         g2 = torch.autograd.grad((layer(x2) * cot).sum(), [x2, layer.weight, layer.bias])
         for a, b in zip(g1, g2):
             assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("net,dtype,tol", [("lstm", torch.float64, 1e-10), ("mlp", torch.float32, 2e-5)])
+@pytest.mark.parametrize("mode", ["mean", "sample"])
+def test_masked_inference_path_equals_autograd_path(net, dtype, tol, mode, monkeypatch):
+    """Without a gradient the masked filter imputes with one HIP launch per step and takes
+    the mixed matrices from the one-step filter kernel; with a gradient it uses torch
+    operations.  Same draws in the same order => same eight outputs."""
+    import kalman_vae_amd.state_space_model as sm
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    T, B = 9, 70
+    ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network=net, hidden_dim=16)
+    ssm = ssm.to(dtype).to(dev).eval()
+    a = (0.5 * torch.randn(T, B, 2, device=dev)).to(dtype)
+    mask = (torch.rand(T, B, device=dev) < 0.6).to(dtype)
+    mask[0] = 1.0
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition=mode, observation=mode)
+    draws, orig = [], sm._standard_normal
+
+    def record(shape, dtype, device):
+        draws.append(orig(shape, dtype=dtype, device=device))
+        return draws[-1]
+
+    monkeypatch.setattr(sm, "_standard_normal", record)
+    with torch.no_grad():
+        fast = ssm.kalman_filter(a, sc, observation_mask=mask)
+    pos = [0]
+
+    def replay(shape, dtype, device):
+        pos[0] += 1
+        assert tuple(draws[pos[0] - 1].shape) == tuple(shape)
+        return draws[pos[0] - 1]
+
+    monkeypatch.setattr(sm, "_standard_normal", replay)
+    slow = ssm.kalman_filter(a.clone().requires_grad_(True), sc, observation_mask=mask)
+    assert pos[0] == len(draws) == (2 * T if mode == "sample" else 0)
+    for x, y in zip(fast, slow):
+        assert x.shape == y.shape
+        assert rel_err(x, y.detach()) < tol
