@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP library against the float64 oracle: random T, B,
+dimensions, masks, options, both small-state families and both large-state families.
+Uses the same checks as tests/test_gpu_kernels.py.  usage: stress_parity.py [cases] [seed]"""
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kernel_checks as KC  # noqa: E402
+from kernel_harness import Backend  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+SMALL = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)]
+LARGE = [(32, 16, 8), (16, 8, 4)]
+if os.environ.get("STRESS_SELF_CHECK"):      # the sweep must notice errors: impossible tolerance
+    KC.TOL[torch.float32] = 1e-9
+be = Backend("hip")
+failures, t0 = [], time.time()
+for i in range(cases):
+    large = rng.random() < 0.3
+    n, p, K = rng.choice(LARGE if large else SMALL)
+    dtype = torch.float32 if (large or rng.random() < 0.6) else torch.float64
+    T = rng.choice([1, 2, 3, 5, 8, 13, 20, 31])
+    B = rng.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 130, 257]) if not large else rng.choice([1, 2, 5, 9])
+    os.environ["KVAE_SEQ_LANES"] = rng.choice(["1", "4"])
+    os.environ["KVAE_LARGE_STATE"] = rng.choice(["tile", "lds"])
+    sym, burn = rng.random() < 0.7, rng.choice([0, 0, 1, 3])
+    burn = min(burn, max(T - 1, 0))
+    kind = rng.choice(["filter", "smooth", "elbo"])
+    desc = (f"{kind} T={T} B={B} n={n} p={p} K={K} {str(dtype)[6:]} lanes={os.environ['KVAE_SEQ_LANES']} "
+            f"large={os.environ['KVAE_LARGE_STATE']} sym={sym} burn_in={burn}")
+    try:
+        if kind == "filter":
+            KC.check_filter(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=1000 + i,
+                            mask_kind=rng.choice(["none", "binary", "fractional"]), symmetrize=sym,
+                            burn_in=burn, per_sequence_carry=rng.random() < 0.3)
+        elif kind == "smooth":
+            KC.check_smooth(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=2000 + i,
+                            sample=rng.random() < 0.7, symmetrize=sym, burn_in=burn)
+        else:
+            KC.check_elbo(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=3000 + i)
+    except Exception as err:  # noqa: BLE001
+        failures.append(desc + " :: " + str(err).replace("\n", " | ")[:300])
+    if (i + 1) % 25 == 0:
+        print(f"{i + 1} cases, {len(failures)} failures, {time.time() - t0:.0f} s", flush=True)
+print("\n".join(failures) if failures else "all cases within tolerance")
+sys.exit(1 if failures else 0)
