@@ -328,10 +328,14 @@ __device__ void elbo_forward_sequence(const ElboFwdArgs<float>& g, int b, float*
     const float m0 = vload<N>(g.m0);
     float zp = 0.f;
     const float c_obs = 0.5f * (float)P * log_2pi<float>(), c_lat = 0.5f * (float)N * log_2pi<float>();
+    // the covariance the step starts with is requested one step ahead: its
+    // factorisation is the first thing every step waits for
+    Tile S_next = load<N, N>(g.Ps + (long)b * N * N);
 #pragma unroll 1
     for (int t = 0; t < g.T; ++t) {
         const long tb = (long)t * B + b;
-        const Tile S = load<N, N>(g.Ps + tb * N * N);
+        const Tile S = S_next;
+        if (t + 1 < g.T) S_next = load<N, N>(g.Ps + (tb + B) * N * N);
         const Tile CT = load_t<P, N>(g.Cs + tb * P * N);
         const float ms = vload<N>(g.ms + tb * N), e = vload<N>(g.eps + tb * N);
         const float a = vload<P>(g.a + tb * P);
@@ -399,13 +403,15 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
     // per iteration, at the top of the loop, for pair t - 1.
     Tile LT = tzero(), Li = tzero();
     float z = 0.f, e = 0.f, dg = 1.f;
+    Tile S_next = load<N, N>(f.Ps + ((long)(T - 1) * B + b) * N * N);   // one step ahead
 #pragma unroll 1
     for (int t = T; t >= 0; --t) {
         Tile LTp = tzero(), Lip = tzero();
         float zp = 0.f, ep = 0.f, dgp = 1.f;
         if (t > 0) {
             const long tp = (long)(t - 1) * B + b;
-            const Tile S = load<N, N>(f.Ps + tp * N * N);
+            const Tile S = S_next;
+            if (t > 1) S_next = load<N, N>(f.Ps + (tp - B) * N * N);
             const float ms = vload<N>(f.ms + tp * N);
             ep = vload<N>(f.eps + tp * N);
             chol<N, true>(S, LTp, Lip, dgp);
@@ -526,6 +532,8 @@ __device__ void smooth_forward_sequence(const SmoothFwdArgs<float>& g, int b, fl
     if (g.eps_o) LRT = load_t<P, P>(g.LR);
     float ms = 0.f;
     Tile Ps = tzero();
+    // the predicted covariance whose factorisation opens a step, requested a step ahead
+    Tile Pn_next = T > 1 ? load<N, N>(g.Pn + ((long)(T - 2) * B + b) * N * N) : tzero();
 #pragma unroll 1
     for (int t = T - 1; t >= 0; --t) {
         const long tb = (long)t * B + b;
@@ -537,7 +545,8 @@ __device__ void smooth_forward_sequence(const SmoothFwdArgs<float>& g, int b, fl
             ms = m;
             Ps = Pf;
         } else {
-            const Tile Pn = load<N, N>(g.Pn + tb * N * N);
+            const Tile Pn = Pn_next;
+            if (t > 0) Pn_next = load<N, N>(g.Pn + (tb - B) * N * N);
             const Tile An = load<N, N>(g.As + (tb + B) * N * N);
             const float mn = vload<N>(g.mn + tb * N);
             Tile LT, Li, Pi, W, JT, X;
@@ -589,12 +598,18 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
     }
     float msb = 0.f;
     Tile G = tzero();
+    // the smoothed covariance of the next step is requested a step ahead: it is both the
+    // first thing the next step factorises and this step's Ps_{t+1}
+    Tile Ps_next = load<N, N>(f.Ps + (long)b * N * N);
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         const long tb = (long)t * B + b;
         const bool last = t == T - 1;
         const float ms = vload<N>(f.ms + tb * N);
-        const Tile Ps = load<N, N>(f.Ps + tb * N * N);
+        const Tile Ps = Ps_next;
+        if (!last) Ps_next = load<N, N>(f.Ps + (tb + B) * N * N);
+        // the predicted covariance is factorised right after the emission adjoint
+        const Tile Pn = last ? tzero() : load<N, N>(f.Pn + tb * N * N);
         if (g.g_ms) msb += vload<N>(g.g_ms + tb * N);
         if (g.g_Ps) tadd(G, load<N, N>(g.g_Ps + tb * N * N));
         // emission adjoint: zs = ms + chol(Ps) eps_s, ares = C zs + LR eps_o
@@ -636,10 +651,9 @@ __device__ void smooth_backward_sequence(const SmoothBwdArgs<float>& g, int b, f
                 G = tzero();
             }
             const Tile Pf = load<N, N>(f.Pf + tb * N * N);
-            const Tile Pn = load<N, N>(f.Pn + tb * N * N);
             const Tile An = load<N, N>(f.As + (tb + B) * N * N);
             const Tile AnT = load_t<N, N>(f.As + (tb + B) * N * N);
-            Tile D = load<N, N>(f.Ps + (tb + B) * N * N);
+            Tile D = Ps_next;
             const float d = vload<N>(f.ms + (tb + B) * N) - vload<N>(f.mn + tb * N);
             Tile LT, Li, Pi, W, WT, J;
             float dg;
@@ -808,11 +822,13 @@ __device__ void filter_backward_sequence(const FilterBwdArgs<float>& g, int b, f
                 load_or_zero<P, N>(g.g_Cs, ((long)T * B + b) * P * N));
     float mpb = 0.f;
     Tile Ppb = tzero();
+    Tile An_next = load<N, N>(f.As + ((long)T * B + b) * N * N);   // a step ahead
 #pragma unroll 1
     for (int t = T - 1; t >= 0; --t) {
         const long tb = (long)t * B + b;
         const Tile C = load<P, N>(f.Cs + tb * P * N), CT = load_t<P, N>(f.Cs + tb * P * N);
-        const Tile An = load<N, N>(f.As + (tb + B) * N * N);
+        const Tile An = An_next;
+        if (t > 0) An_next = load<N, N>(f.As + tb * N * N);
         const float a = vload<P>(f.a + tb * P);
         float mp;
         Tile Pp;
