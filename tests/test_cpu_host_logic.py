@@ -175,3 +175,46 @@ def test_full_model_loads_reference_state_dict(case):
         xs = torch.from_numpy(d["in.xs"])
         q = model.encoder(xs.reshape(-1, *xs.shape[2:]))
         assert rel_err(q.loc.view(cfg["T"], cfg["B"], -1), torch.from_numpy(d["out.as"])) < 1e-12
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """Checkpoints use the reference's dictionary layout (examples/train.py:153-164): a
+    file written here restores model, optimizer and scheduler, and a file with the
+    reference's keys built from a reference-generated state_dict loads strictly."""
+    import json
+    import numpy as np
+    from kalman_vae_amd import KalmanVariationalAutoencoder
+    from kalman_vae_amd.checkpoint import KEYS, load_checkpoint, save_checkpoint
+
+    def make():
+        torch.manual_seed(0)
+        m = KalmanVariationalAutoencoder((16, 16), 1, 2, 4, 3, 0.9, 0.9, True, 0.7, "lstm")
+        opt = torch.optim.Adam(m.parameters(), lr=3e-3)
+        return m, opt, torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+
+    m1, o1, s1 = make()
+    for p in m1.parameters():
+        p.grad = torch.ones_like(p)
+    o1.step()
+    s1.step()
+    path = save_checkpoint(str(tmp_path), 7, m1, o1, s1, train_loss=1.5, test_loss=2.5)
+    assert os.path.basename(path) == "state-7.pth"
+    assert set(torch.load(path, weights_only=True)) == set(KEYS)
+    m2, o2, s2 = make()
+    meta = load_checkpoint(path, m2, o2, s2)
+    assert meta == {"epoch": 7, "train_loss": 1.5, "test_loss": 2.5}
+    for a, b in zip(m1.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    assert s2.last_epoch == s1.last_epoch and o2.state_dict()["state"].keys() == o1.state_dict()["state"].keys()
+
+    # a file in the reference's layout whose state_dict came from the reference's module
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "kvae", "gaussian_lstm_f64.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd.")}
+    ref_file = str(tmp_path / "state-0.pth")
+    torch.save({"epoch": 0, "model_state_dict": sd, "optimizer_state_dict": None,
+                "scheduler_state_dict": None, "train_loss": 0.0, "test_loss": 0.0}, ref_file)
+    cfg = json.loads(str(d["config"]))
+    m3 = KalmanVariationalAutoencoder(tuple(cfg["image"]), cfg["channels"], cfg["p"], cfg["n"],
+                                      cfg["K"], 0.9, 0.9, True, 0.7, cfg["net"], cfg["decoder"]).double()
+    load_checkpoint(ref_file, m3)
+    assert torch.equal(m3.encoder.conv1.weight, sd["encoder.conv1.weight"])
