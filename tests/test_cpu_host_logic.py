@@ -218,3 +218,28 @@ def test_checkpoint_layout_round_trip(tmp_path):
                                       cfg["K"], 0.9, 0.9, True, 0.7, cfg["net"], cfg["decoder"]).double()
     load_checkpoint(ref_file, m3)
     assert torch.equal(m3.encoder.conv1.weight, sd["encoder.conv1.weight"])
+
+
+def test_evaluation_masks_and_pixel_metric():
+    """Mask builders and the incorrect-pixel fraction of the evaluation sweeps against
+    hand-computed values (kvae/evaluation.py:21-41, 272-286)."""
+    from kalman_vae_amd.evaluation import (calculate_fraction_of_incorrect_pixels,
+                                           create_continuous_mask, create_random_mask)
+    m = create_continuous_mask(10, 4, 3, "cpu", torch.float64)
+    assert m.shape == (10, 3) and m.dtype == torch.float64
+    assert m[:, 1].tolist() == [1, 1, 1, 0, 0, 0, 0, 1, 1, 1]      # gap starts at (10 - 4) // 2
+    assert create_continuous_mask(7, 2, 1, "cpu", torch.float32)[:, 0].tolist() == [1, 1, 0, 0, 1, 1, 1]
+    torch.manual_seed(5)
+    r = create_random_mask(6, 50, 0.5, "cpu", torch.float32)
+    torch.manual_seed(5)
+    want = (torch.rand(6, 50) >= 0.5).float()
+    want[0] = 1
+    want[-1] = 1
+    assert torch.equal(r, want) and 0.2 < float(r[1:-1].mean()) < 0.8
+    assert float(create_random_mask(4, 3, 1.0, "cpu", torch.float32)[1:-1].sum()) == 0.0
+    # T=2, B=1, one 1x2x2 frame per step; only step 1 is masked: 1 of its 4 pixels is wrong
+    image = torch.tensor([[[[[1., 0.], [0., 1.]]]], [[[[1., 1.], [0., 0.]]]]])
+    recon = torch.tensor([[[[[.1, .9], [.9, .1]]]], [[[[.9, .8], [.7, .2]]]]])
+    mask = torch.tensor([[1.], [0.]])
+    assert float(calculate_fraction_of_incorrect_pixels(image, recon, mask)) == 0.25
+    assert torch.isnan(calculate_fraction_of_incorrect_pixels(image, recon, torch.ones(2, 1)))

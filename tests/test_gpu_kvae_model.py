@@ -116,3 +116,41 @@ def test_argument_errors():
     m.train()
     with pytest.raises(ValueError):     # the encoder mean is an inference-only choice
         m.elbo(SampleControl(encoder="mean"), xs=torch.zeros(2, 1, 1, 16, 16).cuda())
+
+
+def test_evaluation_sweeps(tmp_path):
+    """The imputation sweeps (kvae/evaluation.py:94-207) on a synthetic batch: table layout,
+    value ranges, nan where nothing is masked, and the same numbers whether the masked
+    filter ran its inference path (the sweeps, no_grad) or its autograd path."""
+    import math
+    from kalman_vae_amd import KalmanVariationalAutoencoder, SampleControl
+    from kalman_vae_amd import evaluation as ev
+    torch.manual_seed(2)
+    dev = torch.device("cuda:0")
+    model = KalmanVariationalAutoencoder((16, 16), 1, 2, 4, 3, 0.9, 0.9, False, 1.0, "lstm",
+                                         decoder_type="bernoulli").to(dev).eval()
+    frames = torch.rand(14, 6, 1, 16, 16)
+    loader = [frames]
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition="mean", observation="mean")
+    rnd, cont = ev.evaluate(loader, model, sc, str(tmp_path), 3, torch.float32, dev)
+    assert list(rnd.columns) == ["batch_id", "dropout_probabilities", "filtering_incorrect_pixels",
+                                 "smoothing_incorrect_pixels"]
+    assert list(cont.columns) == ["batch_id", "mask_lengths", "filtering_incorrect_pixels",
+                                  "smoothing_incorrect_pixels"]
+    assert len(rnd) == 11 and cont["mask_lengths"].tolist() == [2, 4, 6, 8]
+    assert math.isnan(rnd["filtering_incorrect_pixels"][0])          # dropout 0: nothing masked
+    for col in ("filtering_incorrect_pixels", "smoothing_incorrect_pixels"):
+        assert all(0.0 <= v <= 1.0 for v in cont[col])
+        assert all(0.0 <= v <= 1.0 for v in rnd[col][1:])
+    assert (tmp_path / "tables" / "epoch_3" / "random_masking.csv").exists()
+    assert (tmp_path / "tables" / "epoch_3" / "continuous_masking.csv").exists()
+
+    batch = (frames > 0.5).float().to(dev)
+    mask = ev.create_continuous_mask(14, 6, 6, dev, torch.float32)
+    fast = ev._incorrect_pixels(model, batch, mask, sc)
+    _, info = model.elbo(xs=batch, observation_mask=mask, sample_control=sc)      # autograd path
+    slow = []
+    for key in ("filter_as", "as_resampled"):
+        rec = model.decoder(info[key].reshape(14 * 6, -1)).mean.view(batch.shape)
+        slow.append(float(ev.calculate_fraction_of_incorrect_pixels(batch, rec, mask)))
+    assert all(abs(a - b) < 1e-6 for a, b in zip(fast, slow)), (fast, slow)
