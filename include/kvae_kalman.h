@@ -212,6 +212,30 @@ int kvae_impute_observation(const kvae_dims *d, const void *w, const void *A_K, 
                             const void *eps_z, const void *L_Q, const void *eps_a,
                             const void *L_R, void *a_w, void *stream);
 
+/* The masked filter with its weight network evaluated inside the recursion, for the
+ * two-layer perceptron softmax(W2 relu(W1 a + b1) + b2)
+ * (kvae/dynamics_parameter_network.py:61-90 with num_layers = 2): the loop of
+ * kvae/state_space_model.py:219-352 with an observation mask, in one launch.  Per step
+ * the kernel imputes the observation the network sees (as kvae_impute_observation),
+ * evaluates the network on it, and runs the filter step with the weights so obtained.
+ * io as for kvae_filter_forward, except that io->alpha (T+1,B,K) is read only in row 0
+ * (the weights of the first step, uniform in the reference) and rows 1..T are WRITTEN
+ * (the caller owns the buffer; the const in the struct is not honoured here), and
+ * io->mask NULL means nothing is masked.  Forward only (inference).  Small state
+ * dimensions, hidden * (p + 1 + K) + K elements must fit 16 KB.                     */
+typedef struct kvae_masked_mlp {
+    int32_t hidden, _pad;
+    const void *packed; /* hidden rows of [W1[j,0..p-1], b1[j], W2[0..K-1,j]], then b2 (K) */
+    const void *eps_z;  /* (T,B,n) standard-normal draws or NULL ("mean" mode) */
+    const void *L_Q;    /* (n,n) lower Cholesky factor of Q, needed with eps_z */
+    const void *eps_a;  /* (T,B,p) or NULL */
+    const void *L_R;    /* (p,p), needed with eps_a */
+    void *a_w;          /* out (T,B,p): the observations the network saw */
+} kvae_masked_mlp;
+
+int kvae_filter_forward_masked_mlp(const kvae_dims *d, const kvae_filter_fwd *io,
+                                   const kvae_masked_mlp *net, void *stream);
+
 /* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
  * (and of the imputation path kvae/evaluation.py:100-140): runs
  * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream`.

@@ -60,12 +60,15 @@ ElboBwd = _ptr_struct("ElboBwd", [
     "d_mat_As", "d_mat_Cs", "d_Q", "d_R", "d_m0", "d_P0", "g_scale",
     ("g_scale_stride", C.c_int32), ("_pad", C.c_int32),
     ("w_obs", C.c_double), ("w_trans", C.c_double), ("w_post", C.c_double)])
+MaskedMlp = _ptr_struct("MaskedMlp", [
+    ("hidden", C.c_int32), ("_pad", C.c_int32), "packed", "eps_z", "L_Q", "eps_a", "L_R", "a_w"])
 
 EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
     "kvae_filter_forward", "kvae_filter_backward",
     "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
+    "kvae_filter_forward_masked_mlp",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
@@ -168,6 +171,9 @@ def load():
     lib.kvae_softmax_head_backward_blocks.restype = C.c_int
     lib.kvae_impute_observation.argtypes = [C.POINTER(Dims)] + [_vp] * 12
     lib.kvae_impute_observation.restype = C.c_int
+    lib.kvae_filter_forward_masked_mlp.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd),
+                                                   C.POINTER(MaskedMlp), _vp]
+    lib.kvae_filter_forward_masked_mlp.restype = C.c_int
     lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
     lib.kvae_lstm2_prepare.restype = C.c_int
     lib.kvae_lstm2_prepared_elems.argtypes = []

@@ -404,8 +404,11 @@ KV_HD bool update_terms(const R* C, const R* mp, const R* Pp, const R* Rm, const
     return ok;
 }
 
-template <typename R, int N, int P, int K>
-KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b) {
+// `next_weights(t, tb, w, C, mp, a, wn)` supplies the mixing weights of step t+1:
+// read from g.alpha by filter_forward_sequence, computed in the loop when the weight
+// network is evaluated in the kernel (masked sequences, state_space_model.py:232-282).
+template <typename R, int N, int P, int K, typename Next>
+KV_HD void filter_forward_loop(const FilterFwdArgs<R>& g, int b, Next&& next_weights) {
     const long B = g.B;
     R Rm[P * P], Q[N * N];
     gload<R, P * P>(g.Rm, Rm);
@@ -431,9 +434,9 @@ KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b) {
     for (int t = 0; t < g.T; ++t) {
         const long tb = (long)t * B + b;
         R C[P * N], An[N * N], a[P];
-        gload<R, K>(g.alpha + (tb + B) * K, wn);
         gload<R, P>(g.a + tb * P, a);
         mix<R, K, P * N>(w, g.C_K, C);
+        next_weights(t, tb, w, C, mp, a, wn);
         mix<R, K, N * N>(wn, g.A_K, An);
         if (g.Cs) gstore<R, P * N>(g.Cs + tb * P * N, C);
         if (g.As) gstore<R, N * N>(g.As + (tb + B) * N * N, An);
@@ -481,6 +484,86 @@ KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b) {
         *g.status |= st;
 #endif
     }
+}
+
+template <typename R, int N, int P, int K>
+KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b) {
+    const long B = g.B;
+    filter_forward_loop<R, N, P, K>(
+        g, b, [&](int, long tb, const R*, const R*, const R*, const R*, R* wn) {
+            gload<R, K>(g.alpha + (tb + B) * K, wn);
+        });
+}
+
+// The weight network of masked sequences evaluated inside the filter loop, for the
+// two-layer perceptron  softmax(W2 relu(W1 a + b1) + b2)
+// (dynamics_parameter_network.py:61-90 with num_layers = 2).  Per step, before the
+// measurement update (state_space_model.py:232-282):
+//   z = A(w) m_pred (+ L_Q eps_z),  a_imp = C(w) z (+ L_R eps_a),
+//   a_w = mu a + (1 - mu) a_imp,    w_next = net(a_w)
+// `net` is the packed network: per hidden unit j the P entries of W1[j], b1[j] and
+// the K entries of W2[:, j]; then b2.  a_w (T,B,P) and rows 1..T of alpha_out
+// (T+1,B,K) are written; row 0 of alpha_out holds the weights of the first step.
+template <typename R>
+struct MaskedNetArgs {
+    int hidden;
+    const R* net;       // global or LDS copy of the packed network
+    const R *eps_z, *L_Q, *eps_a, *L_R;   // (T,B,N), (N,N), (T,B,P), (P,P); pairs may be null
+    R *a_w, *alpha_out;
+};
+
+template <typename R, int N, int P, int K>
+KV_HD void filter_forward_masked_mlp_sequence(const FilterFwdArgs<R>& g,
+                                              const MaskedNetArgs<R>& q, int b) {
+    const long B = g.B;
+    constexpr int UNIT = P + 1 + K;
+    filter_forward_loop<R, N, P, K>(
+        g, b, [&](int, long tb, const R* w, const R* C, const R* mp, const R* a, R* wn) {
+            R A[N * N], z[N], aw[P];
+            mix<R, K, N * N>(w, g.A_K, A);
+            gemv<R, N, N, false, 0>(A, mp, z);
+            if (q.eps_z) {
+                R e[N], L[N * N];
+                gload<R, N>(q.eps_z + tb * N, e);
+                gload<R, N * N>(q.L_Q, L);
+                gemv<R, N, N, false, 1>(L, e, z);
+            }
+            gemv<R, P, N, false, 0>(C, z, aw);
+            if (q.eps_a) {
+                R e[P], L[P * P];
+                gload<R, P>(q.eps_a + tb * P, e);
+                gload<R, P * P>(q.L_R, L);
+                gemv<R, P, P, false, 1>(L, e, aw);
+            }
+            const R mu = g.mask ? g.mask[tb] : R(1);
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) aw[i] = mu * a[i] + (R(1) - mu) * aw[i];
+            gstore<R, P>(q.a_w + tb * P, aw);
+            R logit[K];
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) logit[k] = q.net[(long)q.hidden * UNIT + k];
+            for (int j = 0; j < q.hidden; ++j) {
+                const R* u = q.net + (long)j * UNIT;
+                R h = u[P];
+                KV_UNROLL
+                for (int i = 0; i < P; ++i) h += u[i] * aw[i];
+                h = h > R(0) ? h : R(0);
+                KV_UNROLL
+                for (int k = 0; k < K; ++k) logit[k] += u[P + 1 + k] * h;
+            }
+            R top = logit[0];
+            KV_UNROLL
+            for (int k = 1; k < K; ++k) top = logit[k] > top ? logit[k] : top;
+            R total = R(0);
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) {
+                wn[k] = exp(logit[k] - top);
+                total += wn[k];
+            }
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) wn[k] /= total;
+            gstore<R, K>(q.alpha_out + (tb + B) * K, wn);
+        });
 }
 
 // ---------------------------------------------------------------------------

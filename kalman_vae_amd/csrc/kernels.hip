@@ -336,6 +336,39 @@ int run_impute(const ImputeArgs<R>& g, hipStream_t s) {
     return launch_status();
 }
 
+// Masked filter with the two-layer perceptron weight network evaluated in the loop
+// (filter_forward_masked_mlp_sequence): the whole T-step recursion of masked sequences
+// is ONE launch, where stepping the network between filter steps takes three launches
+// per time step.  The packed network (a few KB) is staged in LDS; every lane reads the
+// same entry at the same time (broadcast reads).
+constexpr int MASKED_NET_LDS_BYTES = 16 * 1024;
+
+template <typename R, int N, int P, int K>
+__global__ void __launch_bounds__(SEQ_BLOCK)
+filter_forward_masked_mlp_kernel(FilterFwdArgs<R> g, MaskedNetArgs<R> q) {
+    __shared__ __attribute__((aligned(16))) R net[MASKED_NET_LDS_BYTES / sizeof(R)];
+    const int len = q.hidden * (P + 1 + K) + K;
+    for (int e = threadIdx.x; e < len; e += SEQ_BLOCK) net[e] = q.net[e];
+    __syncthreads();
+    q.net = net;
+    const int b = blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (b < g.B) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
+}
+
+template <typename R, int N, int P, int K>
+int run_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd* io,
+                                  const kvae_masked_mlp* net, hipStream_t s) {
+    if ((size_t)(net->hidden * (P + 1 + K) + K) * sizeof(R) > (size_t)MASKED_NET_LDS_BYTES)
+        return KVAE_E_UNSUPPORTED;
+    FilterFwdArgs<R> g = make_args<R>(d, io);
+    MaskedNetArgs<R> q{net->hidden,          (const R*)net->packed, (const R*)net->eps_z,
+                       (const R*)net->L_Q,   (const R*)net->eps_a,  (const R*)net->L_R,
+                       (R*)net->a_w,         (R*)io->alpha};
+    hipLaunchKernelGGL((filter_forward_masked_mlp_kernel<R, N, P, K>), dim3(seq_blocks(d->B)),
+                       dim3(SEQ_BLOCK), 0, s, g, q);
+    return launch_status();
+}
+
 #define KVAE_DISPATCH_CASE(n_, p_, K_)                                  \
     if (d->n == n_ && d->p == p_ && d->K == K_) {                       \
         if (d->dtype == KVAE_F32) return KVAE_CALL(float, n_, p_, K_);  \
@@ -495,6 +528,20 @@ int kvae_impute_observation(const kvae_dims* d, const void* w, const void* A_K, 
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
 #undef KVAE_IMPUTE
+    return KVAE_E_UNSUPPORTED;
+}
+
+int kvae_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd* io,
+                                   const kvae_masked_mlp* net, void* stream) {
+    if (!dims_ok(d) || !io || !io->a || !io->alpha || !io->A_K || !io->C_K || !io->Q || !io->R ||
+        !io->m_in || !io->P_in || !io->mean_filt || !io->cov_filt || !io->mean_pred ||
+        !io->cov_pred || !net || net->hidden < 1 || !net->packed || !net->a_w ||
+        (net->eps_z && !net->L_Q) || (net->eps_a && !net->L_R))
+        return KVAE_E_BADARG;
+#define KVAE_CALL(R, n_, p_, K_) \
+    run_filter_forward_masked_mlp<R, n_, p_, K_>(d, io, net, (hipStream_t)stream)
+    KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
+#undef KVAE_CALL
     return KVAE_E_UNSUPPORTED;
 }
 

@@ -449,6 +449,51 @@ def impute_supported(n, p, K, dtype, device):
     return _impute_kernel_exists[key]
 
 
+def pack_mlp2(first, last):
+    """The two Linear layers of softmax(W2 relu(W1 a + b1) + b2) in the layout
+    kvae_filter_forward_masked_mlp reads: per hidden unit j the row W1[j], b1[j] and the
+    column W2[:, j]; then b2."""
+    units = torch.cat([first.weight, first.bias.unsqueeze(1), last.weight.t()], dim=1)
+    return torch.cat([units.reshape(-1), last.bias]).detach().contiguous()
+
+
+def masked_mlp_fits(hidden, p, K, dtype):
+    """Whether the packed two-layer network fits the 16 KB the kernel stages it in."""
+    return (hidden * (p + 1 + K) + K) * torch.empty((), dtype=dtype).element_size() <= 16 * 1024
+
+
+@torch.no_grad()
+def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z=None, L_Q=None,
+                      eps_a=None, L_R=None, symmetrize=True):
+    """The masked filter (kvae/state_space_model.py:219-352) with a two-layer perceptron
+    weight network evaluated inside the recursion: one launch for all T steps, values
+    only.  Returns (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs, a_w,
+    weights (T+1,B,K)), or None when no kernel is compiled for these dimensions."""
+    capi.require_gpu(a, mask, packed, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R)
+    a, mask, packed, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R = map(
+        _c, (a, mask, packed, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R))
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    dims = _dims(T, B, n, p, K, a.dtype, symmetrize, 0)
+    new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+    m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+    As, Cs, a_w = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p)
+    alpha = new(T + 1, B, K)
+    alpha[0] = 1.0 / K
+    io = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                   m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2),
+                   mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs,
+                   status=status_word(a.device))
+    net = capi.fill(capi.MaskedMlp(), hidden=int(hidden), packed=packed, eps_z=eps_z, L_Q=L_Q,
+                    eps_a=eps_a, L_R=L_R, a_w=a_w)
+    rc = capi.load().kvae_filter_forward_masked_mlp(C.byref(dims), C.byref(io), C.byref(net),
+                                                    capi.current_stream_ptr())
+    if rc == -2:      # KVAE_E_UNSUPPORTED
+        return None
+    capi.check(rc)
+    return m, P, mn, Pn, As, Cs, a_w, alpha
+
+
 def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,
                         want_mats=True):
     return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,

@@ -85,6 +85,9 @@ class StateSpaceModel(nn.Module):
         self._matrix_cache = None   # see cached_matrices()
         self._noise_pool = None     # see _draw()
         self.rng_parity = True      # draw noise exactly like the reference does
+        # masked inference with a two-layer perceptron network: evaluate it inside the
+        # filter kernel (False: step the network between one-step filter launches)
+        self.in_kernel_weight_network = True
         self.check_numerics = True  # raise on a non-positive-definite covariance (host sync)
 
     def _apply(self, fn):
@@ -265,6 +268,14 @@ class StateSpaceModel(nn.Module):
         P_pred = self.initial_state_covariance.expand(B, -1, -1).contiguous()
         if (not torch.is_grad_enabled() and as_.is_cuda
                 and F.impute_supported(self.z_dim, self.a_dim, self.K, as_.dtype, as_.device)):
+            layers = getattr(self.weight_model, "layers", None)
+            if (layers is not None and len(layers) == 2 and self.in_kernel_weight_network
+                    and F.masked_mlp_fits(layers[0].out_features, self.a_dim, self.K, as_.dtype)):
+                # two-layer perceptron: the network runs inside the filter kernel
+                fast = self._filter_masked_mlp(as_, mask, state_noise, obs_noise, symmetrize,
+                                               L_Q, L_R, layers)
+                if fast is not None:
+                    return fast
             fast = self._filter_masked_inference(as_, mask, state_noise, obs_noise, symmetrize,
                                                  w, m_pred, P_pred, L_Q, L_R)
             if fast is not None:
@@ -299,6 +310,32 @@ class StateSpaceModel(nn.Module):
         out["C"].append(mix(w, C_K))
         st = {k: torch.stack(v) for k, v in out.items()}
         return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
+
+    def _filter_masked_mlp(self, as_, mask, state_noise, obs_noise, symmetrize, L_Q, L_R, layers):
+        """The masked filter when no gradient is recorded and the weight network is a
+        two-layer perceptron: ONE launch for the whole sequence, the network evaluated
+        inside the recursion.  The noise is drawn in the order of the step-by-step path
+        (per step: state, then observation).  None when no kernel covers the shapes."""
+        T, B = as_.shape[:2]
+        eps_z = eps_a = None
+        if state_noise or obs_noise:
+            ez, ea = [], []
+            for _ in range(T):
+                if state_noise:
+                    ez.append(self._draw((B, self.z_dim), as_))
+                if obs_noise:
+                    ea.append(self._draw((B, self.a_dim), as_))
+            eps_z = torch.stack(ez) if state_noise else None
+            eps_a = torch.stack(ea) if obs_noise else None
+        out = F.masked_filter_mlp(
+            as_, mask, F.pack_mlp2(layers[0], layers[1]).to(as_.dtype), layers[0].out_features,
+            self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R, self.initial_state_mean,
+            self.initial_state_covariance,
+            eps_z, L_Q, eps_a, L_R, symmetrize=symmetrize)
+        if out is None:
+            return None
+        m, P, mn, Pn, As, Cs, a_w, alpha = out
+        return m, P, mn, Pn, As, Cs, a_w, alpha[:T]
 
     def _filter_masked_inference(self, as_, mask, state_noise, obs_noise, symmetrize, w, m_pred,
                                  P_pred, L_Q, L_R):

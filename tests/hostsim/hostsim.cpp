@@ -69,6 +69,15 @@ int filter_fwd(const kvae_dims* d, const kvae_filter_fwd* io) {
     return 0;
 }
 template <typename R, int N, int P, int K>
+int masked_mlp_fwd(const kvae_dims* d, const kvae_filter_fwd* io, const kvae_masked_mlp* net) {
+    FilterFwdArgs<R> g = mk<R>(d, io);
+    MaskedNetArgs<R> q{net->hidden,        (const R*)net->packed, (const R*)net->eps_z,
+                       (const R*)net->L_Q, (const R*)net->eps_a,  (const R*)net->L_R,
+                       (R*)net->a_w,       (R*)io->alpha};
+    for (int b = 0; b < d->B; ++b) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
+    return 0;
+}
+template <typename R, int N, int P, int K>
 int filter_bwd(const kvae_dims* d, const kvae_filter_bwd* io) {
     using PG = FilterParamGrads<N, P, K>;
     FilterBwdArgs<R> g;
@@ -269,6 +278,17 @@ int hostsim_filter_forward(const kvae_dims* d, const kvae_filter_fwd* io) {
     DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN
+}
+int hostsim_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd* io,
+                                      const kvae_masked_mlp* net) {
+#define FN masked_mlp_fwd
+#undef ARGS
+#define ARGS (d, io, net)
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+#undef ARGS
+#define ARGS (d, io)
 }
 int hostsim_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io) {
 #define FN filter_bwd

@@ -155,10 +155,11 @@ def test_config4_long_large_state_subset(monkeypatch):
     _check_against_oracle(ssm, a, obj, info, g_a, draws, idx, burn_in)
 
 
-def test_config3_masked_imputation_shard_subset(monkeypatch):
+@pytest.mark.parametrize("net", ["lstm", "mlp"])
+def test_config3_masked_imputation_shard_subset(net, monkeypatch):
     from kalman_vae_amd import SampleControl
     T, B, n, p, K = 20, 65536, 4, 2, 3
-    ssm = _model(n, p, K, "lstm", seed=9, train=False)
+    ssm = _model(n, p, K, net, seed=9, train=False)
     g = torch.Generator().manual_seed(10)
     a = (0.7 * torch.randn(T, B, p, generator=g)).to(DEV)
     mask = (torch.rand(T, B, generator=g) > 0.3).float()

@@ -273,12 +273,15 @@ def test_mlp_linear_layer_matches_torch_linear():
             assert rel_err(a, b) < 1e-5
 
 
-@pytest.mark.parametrize("net,dtype,tol", [("lstm", torch.float64, 1e-10), ("mlp", torch.float32, 2e-5)])
+@pytest.mark.parametrize("net,dtype,tol,in_kernel", [
+    ("lstm", torch.float64, 1e-10, False), ("mlp", torch.float32, 2e-5, False),
+    ("mlp", torch.float32, 2e-5, True), ("mlp", torch.float64, 1e-10, True)])
 @pytest.mark.parametrize("mode", ["mean", "sample"])
-def test_masked_inference_path_equals_autograd_path(net, dtype, tol, mode, monkeypatch):
-    """Without a gradient the masked filter imputes with one HIP launch per step and takes
-    the mixed matrices from the one-step filter kernel; with a gradient it uses torch
-    operations.  Same draws in the same order => same eight outputs."""
+def test_masked_inference_path_equals_autograd_path(net, dtype, tol, in_kernel, mode, monkeypatch):
+    """Without a gradient the masked filter either runs as ONE launch with the two-layer
+    perceptron network evaluated inside the recursion (in_kernel), or imputes with one
+    launch per step and takes the mixed matrices from the one-step filter kernel; with a
+    gradient it uses torch operations.  Same draws in the same order => same eight outputs."""
     import kalman_vae_amd.state_space_model as sm
     from kalman_vae_amd import SampleControl, StateSpaceModel
     dev = torch.device("cuda:0")
@@ -286,6 +289,13 @@ def test_masked_inference_path_equals_autograd_path(net, dtype, tol, mode, monke
     T, B = 9, 70
     ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network=net, hidden_dim=16)
     ssm = ssm.to(dtype).to(dev).eval()
+    ssm.in_kernel_weight_network = in_kernel
+    launches = []
+    if net == "mlp":
+        import kalman_vae_amd.functions as Fn
+        orig_one = Fn.masked_filter_mlp
+        monkeypatch.setattr(Fn, "masked_filter_mlp",
+                            lambda *x, **k: launches.append(1) or orig_one(*x, **k))
     a = (0.5 * torch.randn(T, B, 2, device=dev)).to(dtype)
     mask = (torch.rand(T, B, device=dev) < 0.6).to(dtype)
     mask[0] = 1.0
@@ -309,6 +319,7 @@ def test_masked_inference_path_equals_autograd_path(net, dtype, tol, mode, monke
     monkeypatch.setattr(sm, "_standard_normal", replay)
     slow = ssm.kalman_filter(a.clone().requires_grad_(True), sc, observation_mask=mask)
     assert pos[0] == len(draws) == (2 * T if mode == "sample" else 0)
+    assert len(launches) == (1 if in_kernel else 0)
     for x, y in zip(fast, slow):
         assert x.shape == y.shape
         assert rel_err(x, y.detach()) < tol

@@ -113,3 +113,56 @@ def test_wave_f32_large_state(bw):
     KC.check_smooth(bw, T=8, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=2, sample=True)
     KC.check_elbo(bw, T=8, B=2, n=32, p=16, K=8, dtype=torch.float32, seed=3)
     KC.check_elbo(bw, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)
+
+
+# -- masked filter with the two-layer perceptron network inside the loop -----------
+@pytest.mark.parametrize("n,p,K", DIMS)
+@pytest.mark.parametrize("sample", [False, True])
+def test_masked_filter_with_network_in_the_loop(n, p, K, sample):
+    """filter_forward_masked_mlp_sequence (the source of kvae_filter_forward_masked_mlp)
+    against the oracle's masked filter with the same perceptron as its weight function."""
+    import ctypes as C
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd.functions import pack_mlp2
+    from kernel_harness import hostsim_lib
+    from oracle import kalman_oracle as O
+    torch.manual_seed(n * 7 + p)
+    T, B, H, dt = 7, 5, 11, torch.float64
+    first, last = torch.nn.Linear(p, H).to(dt), torch.nn.Linear(H, K).to(dt)
+    A_K = (torch.eye(n) + 0.2 * torch.randn(K, n, n)).to(dt)
+    C_K = (0.5 * torch.randn(K, p, n)).to(dt)
+    Lq, Lr = 0.3 * torch.eye(n) + 0.05 * torch.randn(n, n), 0.3 * torch.eye(p) + 0.05 * torch.randn(p, p)
+    Q, R = (Lq @ Lq.T + 0.01 * torch.eye(n)).to(dt), (Lr @ Lr.T + 0.01 * torch.eye(p)).to(dt)
+    m0, P0 = torch.randn(n).to(dt), (2.0 * torch.eye(n)).to(dt)
+    a = torch.randn(T, B, p).to(dt)
+    mask = (torch.rand(T, B) < 0.6).to(dt)
+    eps_z = torch.randn(T, B, n).to(dt) if sample else None
+    eps_a = torch.randn(T, B, p).to(dt) if sample else None
+    with torch.no_grad():
+        net = lambda x: torch.softmax(last(torch.relu(first(x))), dim=-1)
+        want = O.kalman_filter(a, A_K, C_K, Q, R, m0, P0, net, mask=mask, eps_state=eps_z,
+                               eps_obs=eps_a)
+    new = lambda *s: torch.zeros(s, dtype=dt)
+    m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+    As, Cs, a_w, alpha = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p), new(T + 1, B, K)
+    alpha[0] = 1.0 / K
+    status = torch.zeros(1, dtype=torch.int32)
+    L_Q = torch.linalg.cholesky(Q).contiguous() if sample else None
+    L_R = torch.linalg.cholesky(R).contiguous() if sample else None
+    packed = pack_mlp2(first, last)
+    dims = capi.Dims(T, B, n, p, K, capi.KVAE_F64, 1, 0)
+    io = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                   m_in=m0, P_in=P0, carry_per_sequence=0, mean_filt=m, cov_filt=P, mean_pred=mn,
+                   cov_pred=Pn, mat_As=As, mat_Cs=Cs, status=status)
+    q = capi.fill(capi.MaskedMlp(), hidden=H, packed=packed, eps_z=eps_z, L_Q=L_Q, eps_a=eps_a,
+                  L_R=L_R, a_w=a_w)
+    fn = hostsim_lib().hostsim_filter_forward_masked_mlp
+    fn.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.FilterFwd), C.POINTER(capi.MaskedMlp)]
+    fn.restype = C.c_int
+    assert fn(C.byref(dims), C.byref(io), C.byref(q)) == 0
+    assert int(status[0]) == 0
+    got = {"filter_means": m, "filter_covariances": P, "filter_next_means": mn,
+           "filter_next_covariances": Pn, "mat_As": As, "mat_Cs": Cs, "as_for_weight": a_w,
+           "weights": alpha[:T]}
+    for key, val in got.items():
+        assert KC.rel_err(val, want[key]) < 1e-11, key
