@@ -191,3 +191,41 @@ def check_elbo(backend, T, B, n, p, K, dtype, seed=0):
                   ("d_m0", "m0"), ("d_P0", "P0")):
         _cmp(k, bwd[k], gref[gk], tol, failures)
     assert not failures, "\n".join(failures)
+
+
+def check_masked_mlp(device, T, B, n, p, K, hidden, dtype, seed=0, mask_kind="binary",
+                     sample=False, symmetrize=True):
+    """kvae_filter_forward_masked_mlp (HIP library, through functions.masked_filter_mlp)
+    against the oracle's masked filter whose weight function is the same perceptron."""
+    from kalman_vae_amd import functions as F
+    tol = TOL[dtype]
+    prob = random_problem(T, B, n, p, K, dtype, seed, mask_kind)
+    torch.manual_seed(seed)
+    first, last = torch.nn.Linear(p, hidden).to(dtype), torch.nn.Linear(hidden, K).to(dtype)
+    eps_z = prob["eps_s"] if sample else None
+    eps_a = prob["eps_o"] if sample else None
+    f64 = lambda t: None if t is None else t.double()
+    f1, l1 = first.double(), last.double()      # float64 copies of the rounded parameters
+    with torch.no_grad():
+        net = lambda x: torch.softmax(l1(torch.relu(f1(x))), dim=-1)
+        want = O.kalman_filter(f64(prob["a"]), f64(prob["A_K"]), f64(prob["C_K"]), f64(prob["Q"]),
+                               f64(prob["R"]), f64(prob["m0"]), f64(prob["P0"]), net,
+                               mask=f64(prob["mask"]), eps_state=f64(eps_z), eps_obs=f64(eps_a),
+                               symmetrize=symmetrize)
+        L_Q = torch.linalg.cholesky(f64(prob["Q"])).to(dtype) if sample else None
+        L_R = torch.linalg.cholesky(f64(prob["R"])).to(dtype) if sample else None
+    d = lambda t: None if t is None else t.to(device).contiguous()
+    packed = F.pack_mlp2(f1, l1).to(dtype)
+    got = F.masked_filter_mlp(d(prob["a"]), d(prob["mask"]), d(packed), hidden, d(prob["A_K"]),
+                              d(prob["C_K"]), d(prob["Q"]), d(prob["R"]), d(prob["m0"]),
+                              d(prob["P0"]), d(eps_z), d(L_Q), d(eps_a), d(L_R),
+                              symmetrize=symmetrize)
+    assert got is not None, "no kernel for these dimensions"
+    assert F.read_status(torch.device(device)) == 0
+    names = ["filter_means", "filter_covariances", "filter_next_means", "filter_next_covariances",
+             "mat_As", "mat_Cs", "as_for_weight", "weights"]
+    failures = []
+    for name, val in zip(names, got):
+        val = val[:T] if name == "weights" else val
+        _cmp(name, val.cpu(), want[name], tol, failures)
+    assert not failures, "; ".join(failures)

@@ -164,3 +164,28 @@ def test_lane_long_sequence_drift_f32(be):
                     mask_kind="binary", burn_in=3)
     KC.check_smooth(be, T=1000, B=3, n=4, p=2, K=3, dtype=torch.float32, seed=35, sample=True)
     KC.check_elbo(be, T=1000, B=3, n=4, p=2, K=3, dtype=torch.float32, seed=36)
+
+
+@pytest.mark.parametrize("n,p,K", [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_masked_filter_with_network_in_kernel(n, p, K, dtype):
+    """One-launch masked filter (two-layer perceptron inside the recursion) vs the oracle:
+    binary and fractional masks, no mask, "mean" and "sample" imputation, ragged batch."""
+    KC.check_masked_mlp("cuda:0", T=9, B=67, n=n, p=p, K=K, hidden=24, dtype=dtype, seed=n,
+                        mask_kind="binary", sample=True)
+    KC.check_masked_mlp("cuda:0", T=20, B=130, n=n, p=p, K=K, hidden=128, dtype=dtype, seed=n + 1,
+                        mask_kind="fractional", sample=False, symmetrize=False)
+    KC.check_masked_mlp("cuda:0", T=1, B=1, n=n, p=p, K=K, hidden=5, dtype=dtype, seed=n + 2,
+                        mask_kind="none", sample=True)
+
+
+def test_masked_filter_network_too_large_is_refused():
+    from kalman_vae_amd import functions as F
+    dev = torch.device("cuda:0")
+    z = lambda *s: torch.zeros(*s, device=dev)
+    hidden = 4096      # 4096 * 6 + 3 floats > 16 KB
+    assert not F.masked_mlp_fits(hidden, 2, 3, torch.float32)
+    out = F.masked_filter_mlp(z(2, 3, 2), z(2, 3), z(hidden * 6 + 3), hidden, z(3, 4, 4), z(3, 2, 4),
+                              torch.eye(4, device=dev), torch.eye(2, device=dev), z(4),
+                              torch.eye(4, device=dev))
+    assert out is None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP library against the float64 oracle: random T, B,
-dimensions, masks, options, both small-state families and both large-state families.
+dimensions, masks, options, both small-state families and both large-state families, and the\none-launch masked filter with the perceptron network inside.
 Uses the same checks as tests/test_gpu_kernels.py.  usage: stress_parity.py [cases] [seed]"""
 import os
 import random
@@ -33,7 +33,7 @@ for i in range(cases):
     os.environ["KVAE_LARGE_STATE"] = rng.choice(["tile", "lds"])
     sym, burn = rng.random() < 0.7, rng.choice([0, 0, 1, 3])
     burn = min(burn, max(T - 1, 0))
-    kind = rng.choice(["filter", "smooth", "elbo"])
+    kind = rng.choice(["filter", "smooth", "elbo"] + ([] if large else ["masked_mlp"]))
     desc = (f"{kind} T={T} B={B} n={n} p={p} K={K} {str(dtype)[6:]} lanes={os.environ['KVAE_SEQ_LANES']} "
             f"large={os.environ['KVAE_LARGE_STATE']} sym={sym} burn_in={burn}")
     try:
@@ -41,6 +41,11 @@ for i in range(cases):
             KC.check_filter(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=1000 + i,
                             mask_kind=rng.choice(["none", "binary", "fractional"]), symmetrize=sym,
                             burn_in=burn, per_sequence_carry=rng.random() < 0.3)
+        elif kind == "masked_mlp":
+            KC.check_masked_mlp("cuda:0", T=T, B=B, n=n, p=p, K=K,
+                                hidden=rng.choice([1, 7, 32, 128, 200]), dtype=dtype, seed=4000 + i,
+                                mask_kind=rng.choice(["none", "binary", "fractional"]),
+                                sample=rng.random() < 0.5, symmetrize=sym)
         elif kind == "smooth":
             KC.check_smooth(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=2000 + i,
                             sample=rng.random() < 0.7, symmetrize=sym, burn_in=burn)
