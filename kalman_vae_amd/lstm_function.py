@@ -49,6 +49,33 @@ def _splitk_tn(a, b):
     return main
 
 
+def _slab_plan(R):
+    """(slab count, rows per slab) _splitk_tn uses for R rows, or None when it would not
+    split."""
+    for S in (32, 16, 64):
+        if R % S == 0 and R // S >= 512:
+            return S, R // S
+    return None
+
+
+def _splitk_tn_many(pairs):
+    """[a_i^T @ b_i] for several tall-skinny pairs whose products have the same shape:
+    when every pair splits into the same number of slabs without a remainder, the
+    batched GEMMs write into one buffer and ONE launch sums the slabs of all of them
+    (each launch of a dependent chain costs ~5 us whatever its size)."""
+    plans = [_slab_plan(a.shape[0]) for a, _ in pairs]
+    shapes = {(a.shape[1], b.shape[1]) for a, b in pairs}
+    if None in plans or len({pl[0] for pl in plans}) != 1 or len(shapes) != 1 or len(pairs) < 2:
+        return [_splitk_tn(a, b) for a, b in pairs]
+    S = plans[0][0]
+    (M, N), n = next(iter(shapes)), len(pairs)
+    slabs = torch.empty(S, n, M, N, dtype=pairs[0][0].dtype, device=pairs[0][0].device)
+    for i, ((a, b), (_, chunk)) in enumerate(zip(pairs, plans)):
+        torch.bmm(a.view(S, chunk, M).transpose(1, 2), b.view(S, chunk, N), out=slabs[:, i])
+    sums = capi.column_sum(slabs.view(S, -1)).view(n, M, N)
+    return [sums[i] for i in range(n)]
+
+
 class FusedLSTMFunction(torch.autograd.Function):
     """(x (T,B,in), w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...) ->
     (top-layer h (T,B,H), h_n (L,B,H), c_n (L,B,H))."""
@@ -182,9 +209,12 @@ class FusedLSTM2Function(torch.autograd.Function):
         dw_ih0 = sums[8 * H:].view(4 * H, P)
         d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
         zero = lambda w: torch.zeros_like(w)
-        dw_hh0 = _splitk_tn(d0[B:], h0[:-1].reshape(-1, H)) if T > 1 else zero(w_hh0)
-        dw_ih1 = _splitk_tn(d1, h0.reshape(T * B, H))
-        dw_hh1 = _splitk_tn(d1[B:], h1[:-1].reshape(-1, H)) if T > 1 else zero(w_hh1)
+        if T > 1:
+            dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
+                (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),
+                (d1[B:], h1[:-1].reshape(-1, H))])
+        else:
+            dw_hh0, dw_ih1, dw_hh1 = zero(w_hh0), _splitk_tn(d1, h0.reshape(T * B, H)), zero(w_hh1)
         return dx, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1
 
 
