@@ -946,8 +946,10 @@ KQ_DEV void smooth_backward_quad(const SmoothBwdArgs<R>& g, int b, bool active, 
 // the first quad.
 template <typename R>
 KQ_DEV R sum_over_quads(R v) {
-    KV_UNROLL
-    for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    v += dpp<0x124>(v);   // row_ror:4 and row_ror:8 keep the lane's position in its quad
+    v += dpp<0x128>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 

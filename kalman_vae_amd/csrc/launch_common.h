@@ -12,11 +12,40 @@ namespace kvae {
 
 constexpr int WAVE = 64;
 
+// Lane exchange inside a row of 16 lanes by a DPP control word (no LDS crossbar).
+template <int CTRL>
+__device__ __forceinline__ float row_exchange(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double row_exchange(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_value(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double lane_value(double x, int lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes, the same value in every lane.  Four DPP butterfly stages make
+// each row of 16 uniform (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror);
+// the four row sums are then read with v_readlane.  The shuffle form of this (six
+// ds_bpermute round trips per value) was 40 % of the ELBO backward kernel's cycles.
 template <typename R>
 __device__ __forceinline__ R wave_sum(R v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
+    v += row_exchange<0xB1>(v);
+    v += row_exchange<0x4E>(v);
+    v += row_exchange<0x141>(v);
+    v += row_exchange<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // out[c] = sum_r partial[r][c]; one workgroup per column, fixed summation
