@@ -47,9 +47,18 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&v
     }
 }
 
+// Sum over each row of 16 lanes, in every lane of the row: four DPP butterfly stages
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), no LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float row_exchange(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float sum16(float v) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+    v += row_exchange<0xB1>(v);
+    v += row_exchange<0x4E>(v);
+    v += row_exchange<0x141>(v);
+    v += row_exchange<0x140>(v);
     return v;
 }
 

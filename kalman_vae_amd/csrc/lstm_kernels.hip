@@ -29,6 +29,22 @@
 
 namespace kvae {
 
+// Sum over each row of 16 lanes, in every lane of the row: four DPP butterfly stages
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), no LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float row_exchange16(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += row_exchange16<0xB1>(v);
+    v += row_exchange16<0x4E>(v);
+    v += row_exchange16<0x141>(v);
+    v += row_exchange16<0x140>(v);
+    return v;
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Gate activations on the hardware exp2/rcp units (about 1 ulp each).  The tanh
@@ -950,9 +966,7 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
             }
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                float v = dxp[q];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                const float v = row_sum16(dxp[q]);
                 if (c == 0) dx_part[wave][4 * s + i][q] = v;
             }
         }
