@@ -73,10 +73,19 @@ KT_DEV float bcast(float v, int lane) {
 }
 KT_DEV float other_half(float v) { return __shfl_xor(v, 32, 64); }
 // sum of a lane-form vector's 32 entries (every lane gets the sum)
+template <int CTRL>
+KT_DEV float row_exchange(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 KT_DEV float hsum(float v) {
-    KT_UNROLL
-    for (int m = 16; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    // within each row of 16 lanes by DPP (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+    // row_mirror), then the neighbouring row of the same half through the LDS crossbar
+    v += row_exchange<0xB1>(v);
+    v += row_exchange<0x4E>(v);
+    v += row_exchange<0x141>(v);
+    v += row_exchange<0x140>(v);
+    return v + __shfl_xor(v, 16, 64);
 }
 
 KT_DEV Tile tzero() {
