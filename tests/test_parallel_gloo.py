@@ -132,3 +132,76 @@ def test_data_parallel_step_matches_single_process(tmp_path):
     assert float(obj) > float(first)            # the step ascends the objective
     for k, v in model.state_dict().items():
         assert float((got[k] - v).abs().max()) < 1e-10 * max(1.0, float(v.abs().max())), k
+
+
+# -- masked imputation: the batch is sharded, no collective on the data path --------
+def _masked_problem(seed=5):
+    from kalman_vae_amd import StateSpaceModel
+    torch.manual_seed(seed)
+    model = StateSpaceModel(2, 4, 3, "mlp", hidden_dim=12).double().eval()
+    T, B = 7, 11                                   # ragged: ranks get 6 and 5 sequences
+    a = 0.7 * torch.randn(T, B, 2, dtype=torch.float64)
+    mask = (torch.rand(T, B) < 0.6).double()
+    mask[0] = 1.0
+    return model, a, mask
+
+
+def _masked_filter_host(model, a, mask):
+    """The device source of the one-launch masked filter (perceptron network inside the
+    recursion), compiled for the host by tests/hostsim: the CPU stand-in for the kernel."""
+    import ctypes as C
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd.functions import pack_mlp2
+    from kernel_harness import hostsim_lib
+    T, B, p = a.shape
+    n, K = model.z_dim, model.K
+    new = lambda *s: torch.zeros(s, dtype=a.dtype)
+    out = dict(m=new(T, B, n), P=new(T, B, n, n), mn=new(T, B, n), Pn=new(T, B, n, n),
+               As=new(T + 1, B, n, n), Cs=new(T + 1, B, p, n), a_w=new(T, B, p),
+               alpha=new(T + 1, B, K))
+    out["alpha"][0] = 1.0 / K
+    status = torch.zeros(1, dtype=torch.int32)
+    with torch.no_grad():
+        keep = [t.detach().contiguous() for t in (
+            a, mask, model.mat_A_K, model.mat_C_K, model.mat_Q, model.mat_R,
+            model.initial_state_mean, model.initial_state_covariance,
+            pack_mlp2(model.weight_model.layers[0], model.weight_model.layers[1]))]
+    io = capi.fill(capi.FilterFwd(), a=keep[0], alpha=out["alpha"], mask=keep[1], A_K=keep[2],
+                   C_K=keep[3], Q=keep[4], R=keep[5], m_in=keep[6], P_in=keep[7],
+                   carry_per_sequence=0, mean_filt=out["m"], cov_filt=out["P"],
+                   mean_pred=out["mn"], cov_pred=out["Pn"], mat_As=out["As"], mat_Cs=out["Cs"],
+                   status=status)
+    net = capi.fill(capi.MaskedMlp(), hidden=model.weight_model.layers[0].out_features,
+                    packed=keep[8], eps_z=None, L_Q=None, eps_a=None, L_R=None, a_w=out["a_w"])
+    fn = hostsim_lib().hostsim_filter_forward_masked_mlp
+    fn.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.FilterFwd), C.POINTER(capi.MaskedMlp)]
+    fn.restype = C.c_int
+    dims = capi.Dims(T, B, n, p, K, capi.KVAE_F64, 1, 0)
+    assert fn(C.byref(dims), C.byref(io), C.byref(net)) == 0 and int(status[0]) == 0
+    return torch.cat([out[k].reshape(T, B, -1) for k in ("m", "P", "mn", "Pn", "a_w")], dim=2)
+
+
+def _impute_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, a, mask = _masked_problem()
+    mine = _masked_filter_host(model, shard_batch(a, world, rank).contiguous(),
+                               shard_batch(mask, world, rank).contiguous())
+    torch.save(mine, f"{out}.{rank}")          # every rank keeps its shard: nothing is exchanged
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_masked_imputation_matches_full_batch(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "shard")
+    mp.spawn(_impute_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.cat([torch.load(f"{out}.{r}") for r in range(2)], dim=1)
+    model, a, mask = _masked_problem()
+    want = _masked_filter_host(model, a, mask)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)              # sequences are independent: bit-identical
