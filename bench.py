@@ -121,7 +121,7 @@ def time_lstm_kernels(ssm, a, iters=20):
                               new(T, B, H), new(T, B, H))
     dG0, dG1, dx = torch.empty_like(g0), torch.empty_like(g1), torch.empty_like(x)
     gh = torch.randn(T, B, H, dtype=x.dtype, device=dev) * 1e-3
-    part = new(lib.kvae_lstm2_backward_blocks(B), 4 * H * (2 + P))
+    part = new(lib.kvae_lstm2_backward_blocks(B), 4 * H * (4 + P))
     wih0 = w("weight_ih_l0").contiguous()
     st = capi.current_stream_ptr()
 

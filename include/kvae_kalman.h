@@ -284,8 +284,9 @@ int kvae_lstm_layer_backward(int T, int B, int H, const void *gates, const void 
  *   Wih1, Whh1 as stored (4H,H).  Outputs: dG0, dG1 (T,B,4H), the gate
  *   pre-activation gradients (operands of the caller's three time-batched
  *   recurrent/input weight-gradient GEMMs); dx (T,B,P); and
- *   partial (kvae_lstm2_backward_blocks(B), 4H*(2+P)): per-workgroup sums whose
- *   column sum over the first axis is [ db0 (4H) | db1 (4H) | dWih0 (4H,P) ].
+ *   partial (kvae_lstm2_backward_blocks(B), 4H*(4+P)): per-workgroup sums whose
+ *   column sum over the first axis is [ db0 | db0 | db1 | db1 (4H each) | dWih0 (4H,P) ]
+ *   (each bias sum twice: one copy for bias_ih, one for bias_hh of torch.nn.LSTM).
  */
 int kvae_lstm2_forward(int T, int B, int P, const void *x, const void *Wih0, const void *b0,
                        const void *Whh0T, const void *Wih1T, const void *Whh1T, const void *b1,

@@ -988,7 +988,9 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
         if (t > 0) mfma16_k512(dh0rec, tile0, Whh0, u0);
     }
     // sum the per-lane column accumulators over the four row groups (lane bits 4, 5)
-    float* part = partial + (long)blockIdx.x * (PG4 * (2 + P));
+    // both bias sums are written twice: torch.nn.LSTM has two bias vectors per layer with
+    // the same gradient, and each then gets memory of its own without a copy
+    float* part = partial + (long)blockIdx.x * (PG4 * (4 + P));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -1001,14 +1003,16 @@ lstm2_persistent_backward16_kernel(int T, int B, const float* __restrict__ g_h1,
             b += __shfl_xor(b, 32, 64);
             if (s == 0) {
                 part[col] = a;
-                part[PG4 + col] = b;
+                part[PG4 + col] = a;
+                part[2 * PG4 + col] = b;
+                part[3 * PG4 + col] = b;
             }
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 float w = sw[g][hf][q];
                 w += __shfl_xor(w, 16, 64);
                 w += __shfl_xor(w, 32, 64);
-                if (s == 0) part[2 * PG4 + (long)col * P + q] = w;
+                if (s == 0) part[4 * PG4 + (long)col * P + q] = w;
             }
         }
     }

@@ -196,7 +196,7 @@ class FusedLSTM2Function(torch.autograd.Function):
         g_h1 = g_h1.contiguous()
         dG0, dG1 = torch.empty_like(gates0), torch.empty_like(gates1)
         dx = torch.empty_like(x)
-        partial = torch.empty(lib.kvae_lstm2_backward_blocks(B), 4 * H * (2 + P),
+        partial = torch.empty(lib.kvae_lstm2_backward_blocks(B), 4 * H * (4 + P),
                               dtype=x.dtype, device=x.device)
         wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
         capi.check(lib.kvae_lstm2_backward(
@@ -205,8 +205,10 @@ class FusedLSTM2Function(torch.autograd.Function):
             whh1.data_ptr(), dG0.data_ptr(), dG1.data_ptr(), dx.data_ptr(), partial.data_ptr(),
             capi.current_stream_ptr()))
         sums = capi.column_sum(partial)
-        db0, db1 = sums[:4 * H], sums[4 * H:8 * H]
-        dw_ih0 = sums[8 * H:].view(4 * H, P)
+        # each bias sum comes out twice: separate memory for the gradients of bias_ih and
+        # bias_hh (the same tensor returned twice would be copied by autograd)
+        db0, db0b, db1, db1b = (sums[i * 4 * H:(i + 1) * 4 * H] for i in range(4))
+        dw_ih0 = sums[16 * H:].view(4 * H, P)
         d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
         zero = lambda w: torch.zeros_like(w)
         if T > 1:
@@ -215,7 +217,7 @@ class FusedLSTM2Function(torch.autograd.Function):
                 (d1[B:], h1[:-1].reshape(-1, H))])
         else:
             dw_hh0, dw_ih1, dw_hh1 = zero(w_hh0), _splitk_tn(d1, h0.reshape(T * B, H)), zero(w_hh1)
-        return dx, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1
+        return dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b
 
 
 class SoftmaxHeadFunction(torch.autograd.Function):

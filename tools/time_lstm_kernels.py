@@ -48,7 +48,7 @@ def lstm_kernels(B):
                                           g1.data_ptr(), h1.data_ptr(), c1.data_ptr(), None, None, st))
 
     dx = torch.empty_like(x)
-    part = torch.empty(lib.kvae_lstm2_backward_blocks(B), 4 * H * (2 + P), device=dev)
+    part = torch.empty(lib.kvae_lstm2_backward_blocks(B), 4 * H * (4 + P), device=dev)
 
     def bwd():
         capi.check(lib.kvae_lstm2_backward(T, B, P, gh.data_ptr(), x.data_ptr(), g0.data_ptr(),
