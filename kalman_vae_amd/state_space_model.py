@@ -61,8 +61,10 @@ class StateSpaceModel(nn.Module):
         self._mat_C_K = nn.Parameter((1.0 - wc) * torch.randn(K, a_dim, z_dim)
                                      + wc * torch.eye(a_dim, z_dim))
         # the *unconstrained* square factors are the parameters; Q = L L^T + reg I
-        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(z_dim)))
-        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(a_dim)))
+        # (torch.linalg.cholesky returns a column-major tensor: stored row-major here, so
+        # that the kernels read the parameters in place instead of through a copy per step)
+        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(z_dim)).contiguous())
+        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(init_noise_scale * torch.eye(a_dim)).contiguous())
         self.learn_noise_covariance = learn_noise_covariance
         self.fix_matrices = fix_matrices
         self.Q_reg, self.R_reg = Q_reg, R_reg
@@ -159,13 +161,13 @@ class StateSpaceModel(nn.Module):
     @mat_Q.setter
     def mat_Q(self, value):
         _validate_shape(value, (self.z_dim, self.z_dim), "mat_Q")
-        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(value))
+        self._mat_Q_L = nn.Parameter(torch.linalg.cholesky(value).contiguous())
         self.Q_reg = 0.0
 
     @mat_R.setter
     def mat_R(self, value):
         _validate_shape(value, (self.a_dim, self.a_dim), "mat_R")
-        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(value))
+        self._mat_R_L = nn.Parameter(torch.linalg.cholesky(value).contiguous())
         self.R_reg = 0.0
 
     @mat_A_K.setter
