@@ -36,7 +36,8 @@ enum {
     KVAE_E_BADARG = -1,      /* null required pointer, T < 1, B < 1 ...          */
     KVAE_E_UNSUPPORTED = -2, /* (n,p,K,dtype) has no compiled kernel             */
     KVAE_E_WORKSPACE = -3,   /* workspace smaller than kvae_workspace_bytes()    */
-    KVAE_E_LAUNCH = -4       /* hipGetLastError() after the launch was not ok    */
+    KVAE_E_LAUNCH = -4,      /* hipGetLastError() after the launch was not ok    */
+    KVAE_E_TOOLARGE = -5     /* beyond the fixed scratch of a *_noalloc entry point */
 };
 
 /* bits of the device status word */
@@ -117,6 +118,23 @@ typedef struct {
 
 int kvae_filter_backward(const kvae_dims *d, const kvae_filter_bwd *io,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* kvae_filter_backward for callers that cannot allocate device memory or pass a
+ * workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+ * kvae_filter_backward (bit for bit), but the per-wavefront partial sums of the parameter
+ * gradients live in a fixed array of KVAE_NOALLOC_SCRATCH_BYTES inside the library's code
+ * object (one copy per GPU, held until the process ends) instead of a workspace.  Calls no
+ * hipMalloc / hipFree or any other allocating routine.  Returns KVAE_E_TOOLARGE when
+ * kvae_workspace_bytes(d, KVAE_OP_FILTER_BWD) exceeds the array (at n=4, p=2, K=3, float:
+ * up to 182 000 sequences; large-state shapes, whose workspace grows with T*B*n*n, only
+ * for small batches).  All calls on one GPU share the array: two calls that overlap in
+ * time on the same GPU (different streams) race; calls on one stream are safe.  The first
+ * call on a device looks the array's address up (hipGetSymbolAddress); make it outside
+ * graph capture.                                                                        */
+#define KVAE_NOALLOC_SCRATCH_BYTES (4u << 20)
+size_t kvae_noalloc_scratch_bytes(void);
+int kvae_filter_backward_noalloc(const kvae_dims *d, const kvae_filter_bwd *io, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Smoother: StateSpaceModel.kalman_smooth, kvae/state_space_model.py:375-484.

@@ -66,6 +66,7 @@ MaskedMlp = _ptr_struct("MaskedMlp", [
 EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
     "kvae_filter_forward", "kvae_filter_backward",
+    "kvae_filter_backward_noalloc", "kvae_noalloc_scratch_bytes",
     "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
     "kvae_filter_forward_masked_mlp",
@@ -152,6 +153,10 @@ def load():
     lib.kvae_supported.restype = C.c_int
     lib.kvae_workspace_bytes.argtypes = [C.POINTER(Dims), C.c_int]
     lib.kvae_workspace_bytes.restype = C.c_size_t
+    lib.kvae_filter_backward_noalloc.argtypes = [C.POINTER(Dims), C.POINTER(FilterBwd), _vp]
+    lib.kvae_filter_backward_noalloc.restype = C.c_int
+    lib.kvae_noalloc_scratch_bytes.argtypes = []
+    lib.kvae_noalloc_scratch_bytes.restype = C.c_size_t
     lib.kvae_lstm_layer_forward.argtypes = [C.c_int] * 3 + [_vp] * 5
     lib.kvae_lstm_layer_forward.restype = C.c_int
     lib.kvae_lstm_layer_backward.argtypes = [C.c_int] * 3 + [_vp] * 7

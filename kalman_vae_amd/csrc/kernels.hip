@@ -15,6 +15,7 @@
 
 #include "../../include/kvae_kalman.h"
 #include <cstdlib>
+#include <mutex>
 
 #include "kalman_core.h"
 #include "kalman_quad.h"
@@ -386,6 +387,8 @@ const char* kvae_error_string(int code) {
         case KVAE_E_UNSUPPORTED: return "no kernel compiled for this (n, p, K, dtype)";
         case KVAE_E_WORKSPACE: return "workspace too small, see kvae_workspace_bytes()";
         case KVAE_E_LAUNCH: return "kernel launch failed";
+        case KVAE_E_TOOLARGE:
+            return "problem needs more scratch than the no-allocation entry point holds";
         default: return "unknown error";
     }
 }
@@ -449,6 +452,48 @@ int kvae_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io, void* wo
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
     return wave_filter_backward(d, io, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// kvae_filter_backward for callers that cannot allocate: the per-wavefront partial sums of
+// the parameter gradients go to this array of the code object instead of a caller-provided
+// workspace.  Every GPU the library runs on holds its own copy at its own address; host
+// code may only use the address hipGetSymbolAddress returns on that device (the array's
+// name is a host-side stand-in, not a device address).
+static __device__ __align__(256) unsigned char scratch[KVAE_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_lock;
+void* scratch_address[MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (looked up once per device).
+int static_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return KVAE_E_LAUNCH;
+    std::lock_guard<std::mutex> hold(scratch_lock);
+    if (!scratch_address[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return KVAE_E_LAUNCH;
+        scratch_address[dev] = p;
+    }
+    *out = scratch_address[dev];
+    return KVAE_OK;
+}
+}  // namespace
+
+size_t kvae_noalloc_scratch_bytes(void) { return KVAE_NOALLOC_SCRATCH_BYTES; }
+
+int kvae_filter_backward_noalloc(const kvae_dims* d, const kvae_filter_bwd* io, void* stream) {
+    if (!dims_ok(d)) return KVAE_E_BADARG;
+    const size_t need = kvae_workspace_bytes(d, KVAE_OP_FILTER_BWD);
+    if (need == 0) return KVAE_E_UNSUPPORTED;
+    if (need > KVAE_NOALLOC_SCRATCH_BYTES) return KVAE_E_TOOLARGE;
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != KVAE_OK) return rc;
+    // every wavefront overwrites its own row of partial sums and the row-sum kernel reads
+    // only the rows of this call: nothing of an earlier call has to be cleared
+    return kvae_filter_backward(d, io, ws, need, stream);
 }
 
 int kvae_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, void* stream) {
