@@ -218,6 +218,60 @@ typedef struct {
 int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* The Kalman part of the training objective in one call per direction: what
+ * KalmanVariationalAutoencoder.elbo does between kvae/kalman_vae.py:141 and :260
+ * (kalman_filter, kalman_smooth, zs_distrib.rsample(), the three log-density
+ * terms, aggregate, the weighted sum) when no observation mask makes the mixing
+ * weights depend on the filter state.  That call site keeps three scalars; the
+ * twelve filter / smoother tensors and mat_As / mat_Cs are intermediate values
+ * there, and these entry points never write them: per sequence-step the forward
+ * call reads a, alpha, eps and writes only the state its backward call reads again.
+ *
+ * forward:  out (4) = [ w_obs * sum(obs), w_trans * sum(trans), w_post * sum(post),
+ *   their total ]  with obs / trans / post as in kvae_elbo_forward, computed from
+ *   the smoother's moments of the filter run on (a, alpha, mask); aggregate()'s
+ *   constant (kvae/misc.py:21-41), kalman_weight and the minus sign of the
+ *   posterior term are folded into the three weights.  `saved`:
+ *   kvae_loss_saved_bytes(d) bytes the backward call needs unchanged (filtered,
+ *   predicted and smoothed means and covariances).  terms: (3,T,B) per-pair values,
+ *   or NULL.  mask: (T,B) or NULL; it enters the filter's blend only
+ *   (kvae/state_space_model.py:313-325), the terms ignore it as in the reference.
+ * backward: the cotangents of out[0..2] are g_scale[0], g_scale[stride],
+ *   g_scale[2*stride] (device pointer; stride 0 = one scalar, the cotangent of the
+ *   total); outputs d_a (T,B,p), d_alpha (T+1,B,K) and the parameter gradients summed
+ *   over T and B (overwritten).  d->burn_in as in the separate calls.
+ * Small state dimensions (those kvae_loss_supported() reports).  Deterministic: no
+ * float atomics.                                                                  */
+typedef struct {
+    const void *a;        /* (T,B,p)                                             */
+    const void *alpha;    /* (T+1,B,K)                                           */
+    const void *mask;     /* (T,B) or NULL                                       */
+    const void *A_K, *C_K, *Q, *R;
+    const void *m0, *P0;  /* (n), (n,n): initial_state_mean / covariance         */
+    const void *eps;      /* (T,B,n) standard-normal draw of zs_distrib.rsample()*/
+    void *saved;          /* kvae_loss_saved_bytes(d)                            */
+    void *terms;          /* (3,T,B) or NULL                                     */
+    void *out;            /* (4)                                                 */
+    double w_obs, w_trans, w_post;
+    int32_t *status;
+} kvae_loss_fwd;
+
+typedef struct {
+    kvae_loss_fwd fwd;    /* same pointers as the forward call                   */
+    const void *g_scale;
+    int32_t g_scale_stride, _pad;
+    void *d_a, *d_alpha;
+    void *d_A_K, *d_C_K, *d_Q, *d_R, *d_m0, *d_P0;   /* any may be NULL          */
+} kvae_loss_bwd;
+
+size_t kvae_loss_saved_bytes(const kvae_dims *d);
+int kvae_loss_supported(int n, int p, int K, int dtype);
+int kvae_kalman_loss_forward(const kvae_dims *d, const kvae_loss_fwd *io, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int kvae_kalman_loss_backward(const kvae_dims *d, const kvae_loss_bwd *io, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* One step of the masked filter's imputation, kvae/state_space_model.py:232-277, for
  * every sequence: z = A(w) m_pred (+ L_Q eps_z), a_imp = C(w) z (+ L_R eps_a),
  * a_w = mask * a + (1 - mask) * a_imp, with A(w) = sum_k w[b,k] A_K[k] (C alike).
@@ -390,10 +444,14 @@ int kvae_graph_count_memset_nodes(void *hip_graph);
 int kvae_graph_count_kernel_nodes(void *hip_graph);
 
 /* ------------------------------------------------------------------------ */
-enum { KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3 };
+enum {
+    KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3,
+    KVAE_OP_LOSS_FWD = 4, KVAE_OP_LOSS_BWD = 5
+};
 
-/* Scratch bytes the backward entry points need for their per-wave partial
- * sums of the parameter gradients (0 for an unknown op).                     */
+/* Scratch bytes an entry point with a workspace argument needs (per-wave partial
+ * sums; for KVAE_OP_LOSS_BWD also the gradients handed from its first to its second
+ * sweep); 0 for an unknown op.                                                  */
 size_t kvae_workspace_bytes(const kvae_dims *d, int op);
 
 /* 1 when a kernel for (n,p,K,dtype) is compiled in.                          */

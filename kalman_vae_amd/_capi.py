@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkvae_kalman.so")
 
 KVAE_F32, KVAE_F64 = 0, 1
-OP_FILTER_BWD, OP_SMOOTH_BWD, OP_ELBO_BWD = 1, 2, 3
+OP_FILTER_BWD, OP_SMOOTH_BWD, OP_ELBO_BWD, OP_LOSS_FWD, OP_LOSS_BWD = 1, 2, 3, 4, 5
 
 STATUS_BITS = {
     1: "innovation covariance C P C^T + R is not positive definite",
@@ -60,6 +60,12 @@ ElboBwd = _ptr_struct("ElboBwd", [
     "d_mat_As", "d_mat_Cs", "d_Q", "d_R", "d_m0", "d_P0", "g_scale",
     ("g_scale_stride", C.c_int32), ("_pad", C.c_int32),
     ("w_obs", C.c_double), ("w_trans", C.c_double), ("w_post", C.c_double)])
+LossFwd = _ptr_struct("LossFwd", [
+    "a", "alpha", "mask", "A_K", "C_K", "Q", "R", "m0", "P0", "eps", "saved", "terms", "out",
+    ("w_obs", C.c_double), ("w_trans", C.c_double), ("w_post", C.c_double), "status"])
+LossBwd = _ptr_struct("LossBwd", [
+    ("fwd", LossFwd), "g_scale", ("g_scale_stride", C.c_int32), ("_pad", C.c_int32),
+    "d_a", "d_alpha", "d_A_K", "d_C_K", "d_Q", "d_R", "d_m0", "d_P0"])
 MaskedMlp = _ptr_struct("MaskedMlp", [
     ("hidden", C.c_int32), ("_pad", C.c_int32), "packed", "eps_z", "L_Q", "eps_a", "L_R", "a_w"])
 
@@ -69,6 +75,8 @@ EXPORTS = (
     "kvae_filter_backward_noalloc", "kvae_noalloc_scratch_bytes",
     "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
+    "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_loss_saved_bytes",
+    "kvae_loss_supported",
     "kvae_filter_forward_masked_mlp",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
@@ -123,6 +131,11 @@ def declare(lib, prefix="kvae_", with_stream=True):
         "elbo_forward": [C.POINTER(Dims), C.POINTER(ElboFwd)] + tail,
         "elbo_backward": [C.POINTER(Dims), C.POINTER(ElboBwd)] + (ws + tail if with_stream else []),
     }
+    if hasattr(lib, prefix + "kalman_loss_forward"):
+        spec["kalman_loss_forward"] = ([C.POINTER(Dims), C.POINTER(LossFwd)]
+                                       + (ws + tail if with_stream else []))
+        spec["kalman_loss_backward"] = ([C.POINTER(Dims), C.POINTER(LossBwd)]
+                                        + (ws + tail if with_stream else []))
     for name, argtypes in spec.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes = argtypes
@@ -153,6 +166,10 @@ def load():
     lib.kvae_supported.restype = C.c_int
     lib.kvae_workspace_bytes.argtypes = [C.POINTER(Dims), C.c_int]
     lib.kvae_workspace_bytes.restype = C.c_size_t
+    lib.kvae_loss_saved_bytes.argtypes = [C.POINTER(Dims)]
+    lib.kvae_loss_saved_bytes.restype = C.c_size_t
+    lib.kvae_loss_supported.argtypes = [C.c_int] * 4
+    lib.kvae_loss_supported.restype = C.c_int
     lib.kvae_filter_backward_noalloc.argtypes = [C.POINTER(Dims), C.POINTER(FilterBwd), _vp]
     lib.kvae_filter_backward_noalloc.restype = C.c_int
     lib.kvae_noalloc_scratch_bytes.argtypes = []

@@ -580,8 +580,13 @@ KV_HD void filter_forward_masked_mlp_sequence(const FilterFwdArgs<R>& g,
 //   4. scatter Cbar_t / Abar_{t+1} into d_alpha and the basis gradients.
 // acc holds this lane's running sums of the parameter gradients.
 // ---------------------------------------------------------------------------
-template <typename R, int N, int P, int K>
-KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
+// ACCUM: d_a (T,B,P) and rows 0..T-1 of d_alpha (T+1,B,K) already hold a first part of
+// the gradient (written by the caller's earlier pass over the same sequence) and this
+// pass adds to them; row T of d_alpha is written.  The gradient w.r.t. the initial
+// (m_in, P_in) of the sequence is returned in m_in_bar (N) / P_in_bar (N*N).
+template <typename R, int N, int P, int K, bool ACCUM>
+KV_HD void filter_backward_core(const FilterBwdArgs<R>& g, int b, R* acc, R* m_in_bar,
+                                R* P_in_bar) {
     using PG = FilterParamGrads<N, P, K>;
     const FilterFwdArgs<R>& f = g.f;
     const long B = f.B;
@@ -698,7 +703,15 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
         outer_add<R, N, P>(R(1), mob, u.r, Gb);
         R rb[P];
         gemv<R, P, N, true, 0>(u.G, mob, rb);  // G^T mob
-        gstore<R, P>(g.d_a + tb * P, rb);
+        if (ACCUM) {
+            R da_t[P];
+            gload<R, P>(g.d_a + tb * P, da_t);
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) da_t[i] += rb[i];
+            gstore<R, P>(g.d_a + tb * P, da_t);
+        } else {
+            gstore<R, P>(g.d_a + tb * P, rb);
+        }
         outer_add<R, P, N>(R(-1), rb, mp, Cb);
         gemv<R, N, P, true, 2>(C, rb, mpb);  // mpb -= C^T rb
         // P_obs = Pp - G M ; M = C Pp
@@ -748,6 +761,10 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
                 da[k] = dwn[k] + sA;  // d_alpha[t+1] complete
                 dwn[k] = sC;          // C-part of d_alpha[t]
             }
+            if (ACCUM && t + 1 < T) {
+                KV_UNROLL
+                for (int k = 0; k < K; ++k) da[k] += g.d_alpha[(tb + B) * K + k];
+            }
             gstore<R, K>(g.d_alpha + (tb + B) * K, da);
         }
     }
@@ -765,9 +782,18 @@ KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
                 acc[PG::OFF_A + k * N * N + e] += w0[k] * gA[e];
             }
             da[k] = dwn[k] + s;
+            if (ACCUM) da[k] += g.d_alpha[(long)b * K + k];
         }
         gstore<R, K>(g.d_alpha + (long)b * K, da);
     }
+    vcopy<R, N>(mpb, m_in_bar);
+    vcopy<R, N * N>(Ppb, P_in_bar);
+}
+
+template <typename R, int N, int P, int K>
+KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
+    R mpb[N], Ppb[N * N];
+    filter_backward_core<R, N, P, K, false>(g, b, acc, mpb, Ppb);
     gstore<R, N>(g.d_m_in + (long)b * N, mpb);
     gstore<R, N * N>(g.d_P_in + (long)b * N * N, Ppb);
 }

@@ -446,13 +446,18 @@ struct QFilterAcc {
 template <typename R, int N, int P, int K>
 struct QFilterBwdIn {
     R w[K], wn[K], a[P], mp[N], m[N], mb[N], gmn[N], mu;
+    R da_part[P], dal_part[K];   // ACCUM: what d_a[t], d_alpha[t+1] already hold
     QM<R, N, N> Pp, Pf, Pb, gPn, Ab;
     QM<R, P, N> Cb;
 };
 
-template <typename R, int N, int P, int K>
-KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
-                                 QFilterAcc<R, N, P, K>& acc) {
+// ACCUM: d_a and rows 0..T-1 of d_alpha already hold a first part of the gradient
+// (kalman_core.h: filter_backward_core) and this pass adds to it.  The gradient w.r.t.
+// the initial (m_in, P_in) is returned in m_in_bar (replicated) / P_in_bar.
+template <typename R, int N, int P, int K, bool ACCUM>
+KQ_DEV void filter_backward_quad_core(const FilterBwdArgs<R>& g, int b, bool active,
+                                      QFilterAcc<R, N, P, K>& acc, R* m_in_bar,
+                                      QM<R, N, N>& P_in_bar) {
     const FilterFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
@@ -506,6 +511,14 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
         qload_or_zero<R, N, N>(g.g_As, (tb + B) * N * N, in.Ab);
         qload_or_zero<R, P, N>(g.g_Cs, tb * P * N, in.Cb);
         in.mu = f.mask ? f.mask[tb] : R(1);
+        if (ACCUM) {
+            gload<R, P>(g.d_a + tb * P, in.da_part);
+            if (t + 1 < T) {
+                gload<R, K>(g.d_alpha + (tb + B) * K, in.dal_part);
+            } else {
+                vzero<R, K>(in.dal_part);
+            }
+        }
     };
 
     auto step = [&](int t, const QFilterBwdIn<R, N, P, K>& in) {
@@ -580,7 +593,14 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
         qouter_add<R, N, P>(R(1), mob, u.r, Gb);
         R rb[P];
         mv<R, P, N, true, 0>(u.G, mob, rb);               // G^T mob
-        vstore<R, P>(g.d_a + tb * P, rb, active);
+        if (ACCUM) {
+            R da_t[P];
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) da_t[i] = in.da_part[i] + rb[i];
+            vstore<R, P>(g.d_a + tb * P, da_t, active);
+        } else {
+            vstore<R, P>(g.d_a + tb * P, rb, active);
+        }
         qouter_add<R, P, N>(R(-1), rb, mp, Cb);
         mv<R, N, P, true, 2>(C, rb, mpb);                 // mpb -= C^T rb
         mm<R, N, N, P, false, true, 2>(Pob, u.M, Gb);     // Gb -= Pob M^T
@@ -620,6 +640,7 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
                 KV_UNROLL
                 for (int i = 0; i < P; ++i) acc.C[k][i] += on * w[k] * Cb.c[i];
                 da[k] = dwn[k] + sA;
+                if (ACCUM) da[k] += in.dal_part[k];
                 dwn[k] = sC;
             }
             vstore<R, K>(g.d_alpha + (tb + B) * K, da, active);
@@ -647,9 +668,20 @@ KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
             KV_UNROLL
             for (int i = 0; i < N; ++i) acc.A[k][i] += on * w0[k] * gA.c[i];
             da[k] = dwn[k] + s;
+            if (ACCUM) da[k] += g.d_alpha[(long)b * K + k];
         }
         vstore<R, K>(g.d_alpha + (long)b * K, da, active);
     }
+    vcopy<R, N>(mpb, m_in_bar);
+    qcopy<R, N, N>(Ppb, P_in_bar);
+}
+
+template <typename R, int N, int P, int K>
+KQ_DEV void filter_backward_quad(const FilterBwdArgs<R>& g, int b, bool active,
+                                 QFilterAcc<R, N, P, K>& acc) {
+    R mpb[N];
+    QM<R, N, N> Ppb;
+    filter_backward_quad_core<R, N, P, K, false>(g, b, active, acc, mpb, Ppb);
     vstore<R, N>(g.d_m_in + (long)b * N, mpb, active);
     qstore<R, N, N>(g.d_P_in + (long)b * N * N, Ppb, active);
 }
@@ -955,10 +987,9 @@ KQ_DEV R sum_over_quads(R v) {
 
 // row `row` of the partial-sum matrix (layout FilterParamGrads) from the column sums
 template <typename R, int N, int P, int K>
-KQ_DEV void write_filter_partial(const QFilterAcc<R, N, P, K>& acc, R* partial, long row) {
+KQ_DEV void write_filter_partial_to(const QFilterAcc<R, N, P, K>& acc, R* out) {
     using PG = FilterParamGrads<N, P, K>;
     const int lane = threadIdx.x & 63, q = lane & 3;
-    R* out = partial + row * PG::LEN;
     KV_UNROLL
     for (int k = 0; k < K; ++k) {
         KV_UNROLL
@@ -982,6 +1013,10 @@ KQ_DEV void write_filter_partial(const QFilterAcc<R, N, P, K>& acc, R* partial, 
         const R v = sum_over_quads(acc.Rr[i]);
         if (lane < 4 && q < P) out[PG::OFF_R + i * P + q] = v;
     }
+}
+template <typename R, int N, int P, int K>
+KQ_DEV void write_filter_partial(const QFilterAcc<R, N, P, K>& acc, R* partial, long row) {
+    write_filter_partial_to<R, N, P, K>(acc, partial + row * FilterParamGrads<N, P, K>::LEN);
 }
 
 }  // namespace quad

@@ -142,12 +142,6 @@ __global__ void __launch_bounds__(PAIR_BLOCK) elbo_backward_kernel(ElboBwdArgs<R
 // ---------------------------------------------------------------------------
 // Host side: argument checks, dispatch over the compiled (n,p,K), launches.
 // ---------------------------------------------------------------------------
-#define KVAE_DIM_LIST(X) \
-    X(4, 2, 3)           \
-    X(2, 1, 2)           \
-    X(3, 2, 2)           \
-    X(8, 4, 4)
-
 inline long seq_blocks(long B) { return (B + SEQ_BLOCK - 1) / SEQ_BLOCK; }
 inline long quad_blocks(long B) { return (B + QUAD_SEQS - 1) / QUAD_SEQS; }
 
@@ -424,6 +418,9 @@ size_t kvae_workspace_bytes(const kvae_dims* d, int op) {
             return (size_t)(n <= 4 && p <= 4 ? quad_blocks(d->B) : seq_rows(d->B)) * (p * p) * el;
         case KVAE_OP_ELBO_BWD:
             return (size_t)pair_rows((long)d->T * d->B) * (n * n + p * p + n + n * n) * el;
+        case KVAE_OP_LOSS_FWD:
+        case KVAE_OP_LOSS_BWD:
+            return loss_workspace_bytes(d, op);
         default:
             return 0;
     }

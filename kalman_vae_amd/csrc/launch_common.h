@@ -12,6 +12,14 @@ namespace kvae {
 
 constexpr int WAVE = 64;
 
+// (n, p, K) combinations the small-state kernels (one or four lanes per sequence) are
+// compiled for
+#define KVAE_DIM_LIST(X) \
+    X(4, 2, 3)           \
+    X(2, 1, 2)           \
+    X(3, 2, 2)           \
+    X(8, 4, 4)
+
 // Lane exchange inside a row of 16 lanes by a DPP control word (no LDS crossbar).
 template <int CTRL>
 __device__ __forceinline__ float row_exchange(float x) {
@@ -49,10 +57,10 @@ __device__ __forceinline__ R wave_sum(R v) {
 }
 
 // out[c] = sum_r partial[r][c]; one workgroup per column, fixed summation
-// order.  Columns are routed to up to five output tensors by offset.
+// order.  Columns are routed to up to six output tensors by offset.
 struct ReduceSegments {
-    void* out[5];
-    int begin[6];  // begin[i]..begin[i+1] = columns of out[i]
+    void* out[6];
+    int begin[7];  // begin[i]..begin[i+1] = columns of out[i]
     int count;
 };
 
@@ -226,8 +234,8 @@ void launch_reduce(const void* ws, long rows, int len, int count, void* const* o
                    const int* begin, hipStream_t s) {
     ReduceSegments seg;
     seg.count = count;
-    for (int i = 0; i < 5; ++i) seg.out[i] = i < count ? outs[i] : nullptr;
-    for (int i = 0; i < 6; ++i) seg.begin[i] = i <= count ? begin[i] : len;
+    for (int i = 0; i < 6; ++i) seg.out[i] = i < count ? outs[i] : nullptr;
+    for (int i = 0; i < 7; ++i) seg.begin[i] = i <= count ? begin[i] : len;
     hipLaunchKernelGGL((reduce_rows_kernel<R>), dim3(len), dim3(256), 0, s, (const R*)ws, rows, len,
                        seg);
 }

@@ -23,6 +23,10 @@ int wave_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s
 int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
                        hipStream_t s);
 
+// Fused objective (loss_kernels.hip): workspace of kvae_kalman_loss_forward / _backward
+// (op = KVAE_OP_LOSS_FWD / KVAE_OP_LOSS_BWD), 0 when (n, p, K) has no such kernel.
+size_t loss_workspace_bytes(const kvae_dims* d, int op);
+
 // Register-tile kernels (tile_kernels.hip): fp32, n and p multiples of 8 up to 32.
 // KVAE_E_UNSUPPORTED means "use the LDS kernels".
 int tile_supported(int n, int p, int dtype);

@@ -13,6 +13,7 @@
 
 #include "../../include/kvae_kalman.h"
 #include "../../kalman_vae_amd/csrc/kalman_core.h"
+#include "../../kalman_vae_amd/csrc/kalman_loss.h"
 #include "../../kalman_vae_amd/csrc/kalman_wave.h"
 #include <memory>
 
@@ -139,6 +140,52 @@ int elbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
     std::vector<R> acc(PG::LEN, R(0));
     for (int t = 0; t < d->T; ++t)
         for (int b = 0; b < d->B; ++b) elbo_backward_pair<R, N, P>(g, t, b, acc.data());
+    put<R>(io->d_Q, acc.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, acc.data() + PG::OFF_R, P * P);
+    put<R>(io->d_m0, acc.data() + PG::OFF_M0, N);
+    put<R>(io->d_P0, acc.data() + PG::OFF_P0, N * N);
+    return 0;
+}
+
+template <typename R>
+LossFwdArgs<R> mkl(const kvae_dims* d, const kvae_loss_fwd* io) {
+    LossFwdArgs<R> g;
+    g.T = d->T; g.B = d->B; g.symmetrize = d->symmetrize;
+    g.a = (const R*)io->a; g.alpha = (const R*)io->alpha; g.mask = (const R*)io->mask;
+    g.A_K = (const R*)io->A_K; g.C_K = (const R*)io->C_K; g.Q = (const R*)io->Q;
+    g.Rm = (const R*)io->R; g.m0 = (const R*)io->m0; g.P0 = (const R*)io->P0;
+    g.eps = (const R*)io->eps;
+    loss_saved_pointers<R>(io->saved, d->T, d->B, d->n, g);
+    g.terms = (R*)io->terms; g.partial = nullptr; g.status = io->status;
+    return g;
+}
+template <typename R, int N, int P, int K>
+int loss_fwd(const kvae_dims* d, const kvae_loss_fwd* io) {
+    LossFwdArgs<R> g = mkl<R>(d, io);
+    R sums[3] = {R(0), R(0), R(0)};
+    for (int b = 0; b < d->B; ++b) loss_forward_sequence<R, N, P, K>(g, b, sums);
+    R* out = (R*)io->out;
+    out[0] = (R)io->w_obs * sums[0];
+    out[1] = (R)io->w_trans * sums[1];
+    out[2] = (R)io->w_post * sums[2];
+    out[3] = out[0] + out[1] + out[2];
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int loss_bwd(const kvae_dims* d, const kvae_loss_bwd* io) {
+    using PG = LossParamGrads<N, P, K>;
+    LossBwdArgs<R> g;
+    g.f = mkl<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_scale = (const R*)io->g_scale; g.g_scale_stride = io->g_scale_stride;
+    g.w_obs = (R)io->fwd.w_obs; g.w_trans = (R)io->fwd.w_trans; g.w_post = (R)io->fwd.w_post;
+    g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha; g.partial = nullptr;
+    std::vector<R> bars(loss_bars_elems(d->T, d->B, d->n));
+    loss_bars_pointers<R>(bars.data(), d->T, d->B, d->n, g);
+    std::vector<R> acc(PG::LEN, R(0));
+    for (int b = 0; b < d->B; ++b) loss_backward_sequence<R, N, P, K>(g, b, acc.data());
+    put<R>(io->d_A_K, acc.data() + PG::OFF_A, K * N * N);
+    put<R>(io->d_C_K, acc.data() + PG::OFF_C, K * P * N);
     put<R>(io->d_Q, acc.data() + PG::OFF_Q, N * N);
     put<R>(io->d_R, acc.data() + PG::OFF_R, P * P);
     put<R>(io->d_m0, acc.data() + PG::OFF_M0, N);
@@ -316,6 +363,18 @@ int hostsim_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io) {
 }
 int hostsim_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io) {
 #define FN elbo_bwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_kalman_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io) {
+#define FN loss_fwd
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_kalman_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io) {
+#define FN loss_bwd
     DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN

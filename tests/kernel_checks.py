@@ -193,6 +193,55 @@ def check_elbo(backend, T, B, n, p, K, dtype, seed=0):
     assert not failures, "\n".join(failures)
 
 
+def check_loss(backend, T, B, n, p, K, dtype, seed=0, mask_kind="none", symmetrize=True,
+               burn_in=0, weights=(0.7, 1.3, -0.9), stride=1):
+    """kvae_kalman_loss_forward / _backward (filter -> smoother -> ELBO terms -> weighted
+    totals in one call per direction) against the oracle's three separate stages and its
+    autograd: per-pair terms, the four outputs, d_a, d_alpha and every parameter gradient."""
+    tol = TOL[dtype]
+    prob = random_problem(T, B, n, p, K, dtype, seed, mask_kind)
+    dv = _dev(backend, prob)
+    fwd = backend.loss_forward(dv["a"], dv["alpha"], dv["mask"], dv["A_K"], dv["C_K"], dv["Q"],
+                               dv["R"], dv["m0"], dv["P0"], dv["eps_e"], weights,
+                               symmetrize=symmetrize)
+    assert int(fwd["status"].item()) == 0
+
+    wrt = ["a", "alpha", "A_K", "C_K", "Q", "R", "m0", "P0"]
+    o = _f64(prob, wrt)
+    mask64 = None if prob["mask"] is None else prob["mask"].double()
+    f = O.kalman_filter(o["a"], o["A_K"], o["C_K"], o["Q"], o["R"], o["m0"], o["P0"],
+                        AlphaReplay(o["alpha"]), mask=mask64, symmetrize=symmetrize,
+                        burn_in=burn_in, alpha0=o["alpha"][0])
+    s = O.kalman_smooth(f["filter_means"], f["filter_covariances"], f["filter_next_means"],
+                        f["filter_next_covariances"], f["mat_As"], f["mat_Cs"], o["R"],
+                        symmetrize=symmetrize, burn_in=burn_in)
+    e = O.elbo_terms(o["a"], s["means"], s["covariances"], f["mat_As"], f["mat_Cs"], o["Q"],
+                     o["R"], o["m0"], o["P0"], prob["eps_e"].double())
+    totals = torch.stack([w * e[k].sum() for w, k in zip(weights, ("obs", "trans", "post"))])
+    failures = []
+    for i, k in enumerate(("obs", "trans", "post")):
+        _cmp("terms." + k, fwd["terms"][i], e[k], tol, failures)
+    # the totals are sums of T*B terms of mixed sign: compare on the scale of the terms
+    scale = sum(abs(w) * e[k].abs().sum() for w, k in zip(weights, ("obs", "trans", "post")))
+    got = fwd["out"].double().cpu()
+    if not (float((got[:3] - totals.detach()).abs().max()) < tol * float(scale.detach())):
+        failures.append(f"out[0:3]: {got[:3].tolist()} vs {totals.tolist()}")
+    if not (abs(float(got[3] - totals.sum())) < tol * float(scale.detach())):
+        failures.append(f"out[3]: {float(got[3])} vs {float(totals.sum())}")
+
+    # cotangents of the three weighted totals (stride 1) or of their total (stride 0)
+    cot = torch.tensor([0.8, -1.1, 0.6], dtype=torch.float64) if stride else \
+        torch.tensor([1.7], dtype=torch.float64)
+    loss = (cot * totals).sum() if stride else cot[0] * totals.sum()
+    gref = torch.autograd.grad(loss, [o[k] for k in wrt], allow_unused=True)
+    gref = {k: (torch.zeros_like(o[k]) if g is None else g) for k, g in zip(wrt, gref)}
+    g_scale = cot.to(dtype).to(backend.device).contiguous()
+    bwd = backend.loss_backward(fwd, g_scale, stride, symmetrize=symmetrize, burn_in=burn_in)
+    for k in wrt:
+        _cmp("d_" + k, bwd["d_" + k], gref[k], tol, failures)
+    assert not failures, "\n".join(failures)
+
+
 def check_masked_mlp(device, T, B, n, p, K, hidden, dtype, seed=0, mask_kind="binary",
                      sample=False, symmetrize=True):
     """kvae_filter_forward_masked_mlp (HIP library, through functions.masked_filter_mlp)

@@ -24,7 +24,8 @@ def hostsim_lib():
     if _hostsim is None:
         src = os.path.join(HOSTSIM_DIR, "hostsim.cpp")
         csrc = os.path.join(HERE, "..", "kalman_vae_amd", "csrc")
-        deps = [src, os.path.join(csrc, "kalman_core.h"), os.path.join(csrc, "kalman_wave.h")]
+        deps = [src, os.path.join(csrc, "kalman_core.h"), os.path.join(csrc, "kalman_wave.h"),
+                os.path.join(csrc, "kalman_loss.h")]
         stale = (not os.path.exists(HOSTSIM_LIB)
                  or os.path.getmtime(HOSTSIM_LIB) < max(os.path.getmtime(f) for f in deps))
         if stale:
@@ -181,6 +182,47 @@ class Backend:
         io.fwd = fwd["_io"]
         capi.fill(io, g_obs=g_obs, g_trans=g_trans, g_post=g_post, **out)
         self._call("elbo_backward", d, io, capi.OP_ELBO_BWD)
+        return out
+
+    # -- fused objective: filter -> smoother -> ELBO terms in one call -----------
+    def loss_forward(self, a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, weights,
+                     symmetrize=True, want_terms=True):
+        T, B, p = a.shape
+        n, K = A_K.shape[1], A_K.shape[0]
+        dt = a.dtype
+        d = self.dims(T, B, n, p, K, dt, symmetrize)
+        lib = capi.load() if self.kind == "hip" else None
+        esize = a.element_size()
+        saved_bytes = (lib.kvae_loss_saved_bytes(C.byref(d)) if lib
+                       else T * B * (3 * n + 3 * n * n) * esize)
+        saved = self.new(saved_bytes // esize, dtype=dt)
+        out = dict(out=self.new(4, dtype=dt))
+        if want_terms:
+            out["terms"] = self.new(3, T, B, dtype=dt)
+        st = self.status()
+        io = capi.fill(capi.LossFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                       m0=m0, P0=P0, eps=eps, saved=saved, status=st, **out)
+        io.w_obs, io.w_trans, io.w_post = weights
+        self._call("kalman_loss_forward", d, io, capi.OP_LOSS_FWD)
+        out.update(status=st, saved=saved, _io=io,
+                   _keep=(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps))
+        return out
+
+    def loss_backward(self, fwd, g_scale, stride, symmetrize=True, burn_in=0):
+        a, alpha, mask, A_K, C_K = fwd["_keep"][:5]
+        T, B, p = a.shape
+        n, K = A_K.shape[1], A_K.shape[0]
+        dt = a.dtype
+        d = self.dims(T, B, n, p, K, dt, symmetrize, burn_in)
+        out = dict(d_a=self.new(T, B, p, dtype=dt), d_alpha=self.new(T + 1, B, K, dtype=dt),
+                   d_A_K=self.new(K, n, n, dtype=dt), d_C_K=self.new(K, p, n, dtype=dt),
+                   d_Q=self.new(n, n, dtype=dt), d_R=self.new(p, p, dtype=dt),
+                   d_m0=self.new(n, dtype=dt), d_P0=self.new(n, n, dtype=dt))
+        io = capi.LossBwd()
+        io.fwd = fwd["_io"]
+        capi.fill(io, g_scale=g_scale, g_scale_stride=stride, **out)
+        self._call("kalman_loss_backward", d, io, capi.OP_LOSS_BWD)
+        out["_keep"] = g_scale
         return out
 
     @staticmethod
