@@ -57,7 +57,7 @@ def bouncing_ball_observations(T, B, p, device, seed):
     return torch.stack(out).to(device)
 
 
-def build_model(device, dtype, net, n=4, p=2, K=3):
+def build_model(device, dtype, net, n=4, p=2, K=3, fused=True):
     from kalman_vae_amd import StateSpaceModel
     ssm = StateSpaceModel(a_dim=p, z_dim=n, K=K, dynamics_parameter_network=net)
     ssm.mat_Q = torch.eye(n)   # examples/train.py:73-74 of the reference
@@ -65,6 +65,7 @@ def build_model(device, dtype, net, n=4, p=2, K=3):
     ssm = ssm.to(dtype).to(device).train()
     ssm.rng_parity = False      # one noise tensor per call instead of two per step
     ssm.check_numerics = False  # no host sync inside the step
+    ssm.fused_loss = fused      # filter -> smoother -> ELBO terms: one launch per direction
     return ssm
 
 
@@ -304,6 +305,10 @@ def main():
                     help="time only the six HIP kernels with synthetic mixing weights "
                          "(softmax of N(0,1)); no PyTorch weight network, no autograd glue")
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--separate-kernels", action="store_true",
+                    help="run filter, smoother and ELBO terms as six separate kernels with all "
+                         "their tensors materialised (the drop-in API's path) instead of the "
+                         "fused objective")
     ap.add_argument("--no-hip-graph", action="store_true",
                     help="run the step eagerly instead of replaying it as one HIP graph")
     args = ap.parse_args()
@@ -335,7 +340,7 @@ def main():
     dtype = torch.float32
     torch.manual_seed(0)   # same initial parameters on every rank
     n, p, K = args.state_dim, args.obs_dim, args.bases
-    ssm = build_model(dev, dtype, args.net, n, p, K)
+    ssm = build_model(dev, dtype, args.net, n, p, K, fused=not args.separate_kernels)
     a = bouncing_ball_observations(T, B, p, dev, seed=1000 + rank).to(dtype).requires_grad_(True)
     bucket = FlatGradBucket(ssm.parameters()) if world > 1 else None
     sc = SampleControl()

@@ -413,6 +413,95 @@ class KalmanElboObjectiveFunction(torch.autograd.Function):
         return d_a, d_ms, d_Ps, d_As, d_Cs, d_Q, d_R, d_m0, d_P0, None, None, None, None
 
 
+class KalmanLossFunction(torch.autograd.Function):
+    """Filter -> smoother -> ELBO terms -> weighted totals as ONE autograd node and one
+    kernel launch per direction (kvae_kalman_loss_forward / _backward; the sequence of
+    kvae/kalman_vae.py:141-260 without an observation mask feeding the weight network):
+    (a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps; w_obs, w_trans, w_post) ->
+    (objective, weighted totals (3,), terms (3,T,B) or an empty tensor).
+    None of the twelve filter / smoother tensors is materialised; the forward pass keeps
+    one opaque buffer of filtered / predicted / smoothed moments for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, w_obs, w_trans, w_post,
+                symmetrize, burn_in, want_terms):
+        capi.require_gpu(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps)
+        a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps = map(
+            _c, (a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps))
+        lib = capi.load()
+        T, B, p = a.shape
+        K, n = A_K.shape[0], A_K.shape[1]
+        if alpha.shape != (T + 1, B, K):
+            raise ValueError(f"alpha must have shape {(T + 1, B, K)}, got {tuple(alpha.shape)}")
+        if not lib.kvae_loss_supported(n, p, K, capi.dtype_code(a.dtype)):
+            raise NotImplementedError(
+                f"no fused-objective kernel compiled for z_dim={n}, a_dim={p}, K={K}")
+        dims = capi.Dims(T, B, n, p, K, capi.dtype_code(a.dtype), int(bool(symmetrize)),
+                         int(max(0, burn_in)))
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        saved = torch.empty(lib.kvae_loss_saved_bytes(C.byref(dims)), dtype=torch.uint8,
+                            device=a.device)
+        terms = new(3, T, B) if want_terms else None
+        out = new(4)
+        io = capi.fill(capi.LossFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                       m0=m0, P0=P0, eps=eps, saved=saved, terms=terms, out=out,
+                       status=status_word(a.device))
+        io.w_obs, io.w_trans, io.w_post = float(w_obs), float(w_trans), float(w_post)
+        ws, nbytes = _workspace(dims, capi.OP_LOSS_FWD, a.device)
+        capi.check(lib.kvae_kalman_loss_forward(C.byref(dims), C.byref(io), ws.data_ptr(), nbytes,
+                                                capi.current_stream_ptr()))
+        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, saved)
+        ctx.dims, ctx.weights = dims, (float(w_obs), float(w_trans), float(w_post))
+        ctx.set_materialize_grads(False)
+        if terms is None:
+            terms = a.new_empty(0)
+        ctx.mark_non_differentiable(terms)
+        return out[3], out[:3], terms
+
+    @staticmethod
+    def backward(ctx, g_objective, g_weighted, _g_terms):
+        if g_objective is None and g_weighted is None:
+            return (None,) * 16
+        a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, saved = ctx.saved_tensors
+        if g_weighted is None:
+            scale, stride = g_objective.contiguous(), 0
+        else:
+            scale = g_weighted if g_objective is None else g_weighted + g_objective
+            scale, stride = scale.contiguous(), 1
+        dims = ctx.dims
+        T, B, n, p, K = dims.T, dims.B, dims.n, dims.p, dims.K
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        d_a, d_alpha = new(T, B, p), new(T + 1, B, K)
+        d_A_K, d_C_K, d_Q, d_R = new(K, n, n), new(K, p, n), new(n, n), new(p, p)
+        need = ctx.needs_input_grad
+        d_m0 = new(n) if need[7] else None
+        d_P0 = new(n, n) if need[8] else None
+        io = capi.LossBwd()
+        capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m0=m0, P0=P0,
+                  eps=eps, saved=saved)
+        io.fwd.w_obs, io.fwd.w_trans, io.fwd.w_post = ctx.weights
+        capi.fill(io, g_scale=scale, g_scale_stride=stride, d_a=d_a, d_alpha=d_alpha,
+                  d_A_K=d_A_K, d_C_K=d_C_K, d_Q=d_Q, d_R=d_R, d_m0=d_m0, d_P0=d_P0)
+        ws, nbytes = _workspace(dims, capi.OP_LOSS_BWD, a.device)
+        capi.check(capi.load().kvae_kalman_loss_backward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                         nbytes, capi.current_stream_ptr()))
+        return (d_a, d_alpha, None, d_A_K, d_C_K, d_Q, d_R, d_m0, d_P0, None, None, None, None,
+                None, None, None)
+
+
+def kalman_loss(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, w_obs, w_trans, w_post,
+                symmetrize=True, burn_in=0, want_terms=False):
+    """(objective, weighted totals (3,), terms (3,T,B) or empty): see KalmanLossFunction."""
+    return KalmanLossFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, float(w_obs),
+                                    float(w_trans), float(w_post), bool(symmetrize), int(burn_in),
+                                    bool(want_terms))
+
+
+def loss_supported(n, p, K, dtype):
+    """Whether the fused objective has a kernel for these dimensions."""
+    return bool(capi.load().kvae_loss_supported(n, p, K, capi.dtype_code(dtype)))
+
+
 @torch.no_grad()
 def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a=None, L_R=None):
     """One step of the masked filter's imputation for every sequence in one launch

@@ -87,6 +87,10 @@ class StateSpaceModel(nn.Module):
         self._matrix_cache = None   # see cached_matrices()
         self._noise_pool = None     # see _draw()
         self.rng_parity = True      # draw noise exactly like the reference does
+        # kalman_elbo: compute the objective with the one-launch-per-direction kernels that
+        # never materialise the filter / smoother tensors (info then holds None for them)
+        self.fused_loss = False
+        self.fused_loss_terms = False   # also return the per-(t,b) terms from that path
         # masked inference with a two-layer perceptron network: evaluate it inside the
         # filter kernel (False: step the network between one-step filter launches)
         self.in_kernel_weight_network = True

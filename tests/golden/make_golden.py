@@ -50,6 +50,10 @@ def build_case(ref, name, cfg):
         m0 = 0.3 * torch.randn(n)
         W = torch.randn(n, n)
         P0 = 0.5 * torch.eye(n) + 0.1 * W @ W.T
+        if cfg.get("symmetric_init", False):
+            # W @ W.T in float32 is symmetric only up to rounding (1e-8); the reference inverts
+            # the full innovation matrix, a Cholesky-based inverse reads one triangle
+            P0 = 0.5 * (P0 + P0.T)
     ssm = StateSpaceModel(
         a_dim=p, z_dim=n, K=K,
         dynamics_parameter_network=cfg["net"],
@@ -155,7 +159,9 @@ def build_case(ref, name, cfg):
     cots = {k: torch.randn(info[k].shape, generator=g).to(dtype) for k in out_names}
     loss = objective
     for k in out_names:
-        if info[k].requires_grad:
+        # "objective_only": the gradients a training step takes (examples/train.py:128-131
+        # of the reference differentiates -elbo and nothing else)
+        if info[k].requires_grad and not cfg.get("objective_only", False):
             loss = loss + (cots[k] * info[k]).sum()
     params = {"as_": a, "_mat_A_K": ssm._mat_A_K, "_mat_C_K": ssm._mat_C_K,
               "_mat_Q_L": ssm._mat_Q_L, "_mat_R_L": ssm._mat_R_L}
@@ -265,6 +271,26 @@ def cases():
                            state_transition="sample", observation="sample", burn_in=1)
     c["dims_n6p3k2_f64"] = dict(base, seed=22, n=6, p=3, K=2, mask="random",
                                 general_noise=True, learn_noise_covariance=True)
+    # the training call (examples/train.py:115-131): train mode, every path sampled, no mask,
+    # burn-in, gradients of the objective alone
+    tr = dict(base, train_mode=True, state_transition="sample", observation="sample",
+              objective_only=True, burn_in=3, T=20, B=4, identity_noise_via_setter=True)
+    c["train_lstm_f64"] = dict(tr, net="lstm", seed=30)
+    c["train_lstm_f32"] = dict(tr, net="lstm", seed=30, dtype="float32")
+    c["train_mlp_warmup_f64"] = dict(tr, net="mlp", seed=31, learn_weight_model=False, T=9)
+    c["train_general_f64"] = dict(base, net="lstm", seed=32, train_mode=True,
+                                  state_transition="sample", observation="sample",
+                                  objective_only=True, burn_in=2, T=9, B=5, general_noise=True,
+                                  general_init=True, symmetric_init=True,
+                                  learn_noise_covariance=True, init_reg=0.8,
+                                  sequence_operation="sum", kalman_weight=0.8)
+    c["train_nosym_n3_f64"] = dict(base, seed=33, n=3, p=2, K=2, train_mode=True,
+                                   state_transition="sample", observation="sample",
+                                   objective_only=True, symmetrize=False, T=8, B=3,
+                                   general_noise=True, learn_noise_covariance=True)
+    c["train_n8_f64"] = dict(base, seed=34, n=8, p=4, K=4, T=6, B=2, net="lstm", train_mode=True,
+                             state_transition="sample", observation="sample",
+                             objective_only=True, burn_in=1)
     return c
 
 

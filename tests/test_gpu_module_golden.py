@@ -61,21 +61,22 @@ def replay_draws(g, dtype, device):
     return [e.to(dtype).to(device) for e in seq]
 
 
-def run_module(g, dtype, monkeypatch):
+def run_module(g, dtype, monkeypatch, fused=False):
     # MIOpen refuses the backward of an fp32 LSTM that ran in eval mode (the
     # reference on a GPU hits the same limit); these fixtures differentiate
     # eval-mode runs, so use PyTorch's native LSTM kernels for them.
     with torch.backends.cudnn.flags(enabled=False):
-        return _run_module(g, dtype, monkeypatch)
+        return _run_module(g, dtype, monkeypatch, fused)
 
 
-def _run_module(g, dtype, monkeypatch):
+def _run_module(g, dtype, monkeypatch, fused=False):
     import kalman_vae_amd.elbo as ke
     import kalman_vae_amd.state_space_model as ssm_mod
     from kalman_vae_amd import SampleControl, kalman_elbo
     device = torch.device("cuda:0")
     c = g.cfg
     ssm = build_module(g, dtype, device)
+    ssm.fused_loss = ssm.fused_loss_terms = fused
     draws = replay_draws(g, dtype, device)
     pos = [0]
 
@@ -99,7 +100,8 @@ def _run_module(g, dtype, monkeypatch):
     assert pos[0] == len(draws), "module drew fewer random tensors than the reference"
     loss = obj
     for k in OUT_KEYS:
-        if info[k].requires_grad:
+        # "objective_only" fixtures hold the gradients of the objective alone (a training step)
+        if not c.get("objective_only", False) and info[k].requires_grad:
             loss = loss + (g["cot." + k].to(dtype).to(device) * info[k]).sum()
     params = {"as_": a, "_mat_A_K": ssm._mat_A_K, "_mat_C_K": ssm._mat_C_K,
               "_mat_Q_L": ssm._mat_Q_L, "_mat_R_L": ssm._mat_R_L}
@@ -109,7 +111,7 @@ def _run_module(g, dtype, monkeypatch):
     return obj, info, dict(zip(params.keys(), grads))
 
 
-def compare(g_ref, obj, info, grads, tol):
+def compare(g_ref, obj, info, grads, tol, fused=False):
     failures = []
 
     def cmp(name, got, want):
@@ -118,6 +120,9 @@ def compare(g_ref, obj, info, grads, tol):
             failures.append(f"{name}: {e:.3e}")
 
     for k in OUT_KEYS + ["weights"]:
+        if fused and k != "weights":
+            assert info[k] is None, k     # the fused objective materialises none of them
+            continue
         cmp("out." + k, info[k], g_ref["out." + k])
     for i, k in enumerate(("elbo_obs", "elbo_trans", "elbo_post")):
         cmp("out." + k, info["elbo_terms"][i], g_ref["out." + k])
@@ -164,6 +169,45 @@ def test_module_matches_reference_f32(name, monkeypatch):
     g = Golden(name)
     obj, info, grads = run_module(g, torch.float32, monkeypatch)
     compare(g, obj, info, grads, 3e-4)
+
+
+# -- the fused objective (one launch per direction) on the reference's training call ------
+TRAIN = [n for n in golden_names("train_*")]
+
+
+@pytest.mark.parametrize("name", [n for n in TRAIN if n.endswith("_f64")])
+@pytest.mark.parametrize("lanes", ["1", "4"])
+def test_fused_objective_matches_reference_f64(name, lanes, monkeypatch):
+    """kalman_elbo(fused=True) replays the fixtures of the reference's training call:
+    the objective, the three aggregated and per-pair terms and the gradient of the
+    objective w.r.t. the observations, the bases, the noise factors and every
+    weight-network parameter, with the reference's random draws in its draw order."""
+    monkeypatch.setenv("KVAE_SEQ_LANES", lanes)
+    g = Golden(name)
+    obj, info, grads = run_module(g, torch.float64, monkeypatch, fused=True)
+    compare(g, obj, info, grads, 2e-8, fused=True)
+
+
+@pytest.mark.parametrize("name", [n for n in TRAIN if n.endswith("_f64")])
+def test_fused_objective_f32_error_against_f64_reference(name, monkeypatch):
+    g = Golden(name)
+    obj, info, grads = run_module(g, torch.float32, monkeypatch, fused=True)
+    compare(g, obj, info, grads, 1e-4, fused=True)
+
+
+@pytest.mark.parametrize("name", [n for n in TRAIN if n.endswith("_f32")])
+def test_fused_objective_matches_reference_f32(name, monkeypatch):
+    g = Golden(name)
+    obj, info, grads = run_module(g, torch.float32, monkeypatch, fused=True)
+    compare(g, obj, info, grads, 3e-4, fused=True)
+
+
+def test_fused_objective_falls_back_with_a_mask(monkeypatch):
+    """With an observation mask the weights depend on the filter state: fused=True must
+    take the step-by-step path and still return every tensor."""
+    g = Golden("g2_random_mask_f64")
+    obj, info, grads = run_module(g, torch.float64, monkeypatch, fused=True)
+    compare(g, obj, info, grads, 2e-8)
 
 
 def test_errors_match_reference():

@@ -68,7 +68,8 @@ def test_oracle_matches_reference(name):
     assert rel_err(obj, g["out.objective"]) < tol
     loss = obj
     for ok, gk in OUT_MAP.items():
-        if g.has("cot." + gk) and info[ok].requires_grad:
+        if (g.has("cot." + gk) and info[ok].requires_grad
+                and not g.cfg.get("objective_only", False)):
             loss = loss + (g["cot." + gk] * info[ok]).sum()
     grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
     for (k, _), gv in zip(params.items(), grads):
