@@ -377,6 +377,31 @@ int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, co
                         const void *Whh0, const void *Wih1, const void *Whh1, void *dG0, void *dG1,
                         void *dx, void *partial, void *stream);
 
+/* One layer of that network's LSTM (hidden size 128) over a whole sequence in ONE launch
+ * per direction, with the layer's 128 x 512 recurrent matrix held in registers for all T
+ * steps (nothing is streamed from L2 inside the time loop).  Same function as one layer of
+ * torch.nn.LSTM, kvae/dynamics_parameter_network.py:46-58.  float32.
+ * forward: P in 1..4: the layer input x (T,B,P) is projected in the kernel with Wih (4H,P)
+ *   and bias (4H) = b_ih + b_hh; P == 0: gates (T,B,4H) holds the input projection (bias
+ *   included, one time-batched library GEMM by the caller) on entry.  WhhT: W_hh transposed,
+ *   (H,4H).  store_gates != 0: the activated gates i,f,g,o of every step are written to
+ *   gates (in place for P == 0); h, c: (T,B,H) outputs.  h_init / c_init: (B,H) state to
+ *   start from, both NULL for the zero state.
+ * backward: g_h (T,B,H) gradient w.r.t. every h_t from above; gates, c as the forward call
+ *   left them; c_init as in the forward call; Whh (4H,H) as stored.  Outputs: dG (T,B,4H),
+ *   the gate pre-activation gradients (operands of the caller's time-batched weight-gradient
+ *   GEMMs and of the product that carries the gradient to the layer below);
+ *   partial (kvae_lstm128_blocks(B), 4H*(2+P)): per-workgroup sums whose column sum over the
+ *   first axis is [ db | db (4H each: bias_ih and bias_hh) | dWih (4H,P) ]; for P > 0 also
+ *   dx (T,B,P) = dG Wih.                                                                */
+int kvae_lstm128_blocks(int B);
+int kvae_lstm128_forward(int T, int B, int P, const void *x, const void *Wih, const void *bias,
+                         const void *WhhT, void *gates, void *h, void *c, const void *h_init,
+                         const void *c_init, int store_gates, void *stream);
+int kvae_lstm128_backward(int T, int B, int P, const void *x, const void *Wih, const void *gates,
+                          const void *c, const void *c_init, const void *g_h, const void *Whh,
+                          void *dG, void *dx, void *partial, void *stream);
+
 /* Softmax head of the dynamics-parameter network, alpha = softmax(h W^T + b):
  * kvae/dynamics_parameter_network.py:57-58 (LSTMModel) and 84-90 (last layer of
  * MLPModel).  float32; h (R,H) with R = T*B rows and H in {32,64,128,256};

@@ -81,6 +81,7 @@ EXPORTS = (
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
+    "kvae_lstm128_blocks", "kvae_lstm128_forward", "kvae_lstm128_backward",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
     "kvae_softmax_head_backward_blocks",
     "kvae_cholesky_forward", "kvae_cholesky_backward", "kvae_noise_factors",
@@ -184,6 +185,12 @@ def load():
     lib.kvae_lstm2_backward_blocks.argtypes = [C.c_int]
     lib.kvae_lstm2_backward_blocks.restype = C.c_int
     lib.kvae_lstm2_backward.restype = C.c_int
+    lib.kvae_lstm128_blocks.argtypes = [C.c_int]
+    lib.kvae_lstm128_blocks.restype = C.c_int
+    lib.kvae_lstm128_forward.argtypes = [C.c_int] * 3 + [_vp] * 9 + [C.c_int, _vp]
+    lib.kvae_lstm128_forward.restype = C.c_int
+    lib.kvae_lstm128_backward.argtypes = [C.c_int] * 3 + [_vp] * 11
+    lib.kvae_lstm128_backward.restype = C.c_int
     lib.kvae_softmax_head_forward.argtypes = ([C.c_long, C.c_int, C.c_int] + [_vp] * 4
                                               + [C.c_long, _vp])
     lib.kvae_softmax_head_forward.restype = C.c_int

@@ -1,0 +1,52 @@
+// Helpers shared by the LSTM translation units (lstm_kernels.hip, lstm_resident.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace kvae {
+
+// Sum over each row of 16 lanes, in every lane of the row: four DPP butterfly stages
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), no LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float row_exchange16(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += row_exchange16<0xB1>(v);
+    v += row_exchange16<0x4E>(v);
+    v += row_exchange16<0x141>(v);
+    v += row_exchange16<0x140>(v);
+    return v;
+}
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Gate activations on the hardware exp2/rcp units (about 1 ulp each).  The tanh
+// form has an absolute error near 1e-7 around 0, which is what fp32 gate sums
+// carry anyway; both saturate cleanly (exp2 -> inf gives rcp -> 0).
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008f * x));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Streaming accesses for tensors that pass through once (activations saved for the
+// backward pass, gate gradients): keeping them out of the L2's way leaves it to the
+// weights every workgroup re-reads each step.
+__device__ __forceinline__ void store_streaming(float* p, float2 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+}
+__device__ __forceinline__ float2 load_streaming(const float* p) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return make_float2(w[0], w[1]);
+}
+
+
+}  // namespace kvae

@@ -1,0 +1,518 @@
+// One LSTM layer (hidden size 128) over a whole sequence in ONE launch per direction,
+// with the layer's recurrent matrix held in registers for all T steps.
+//
+// Reference: the recurrence of torch.nn.LSTM as used by the dynamics-parameter network
+// (kvae/dynamics_parameter_network.py:46-58; gate order i, f, g, o).
+//
+// The 128 x 512 recurrent matrix is 256 KiB: too large for the 160 KiB LDS of a compute
+// unit, but a compute unit has 512 KiB of vector registers.  A workgroup of four
+// wavefronts (one per SIMD, 512 registers per lane each) owns 16 sequences; wavefront w
+// owns hidden units [32w, 32w+32) and keeps its 128 x 128 slice of the matrix in 256
+// registers per lane, laid out as the B operands of v_mfma_f32_16x16x4_f32 (exact fp32),
+// so a step issues 256 matrix instructions whose operands are all registers plus one LDS
+// read per four of them -- nothing is streamed from L2 inside the time loop.  h_t is
+// exchanged between the wavefronts through LDS (double buffered, one barrier per step),
+// c_t stays in registers.  A lane owns rows 4s..4s+3 (s = lane >> 4) and the adjacent
+// hidden units ub, ub+1 (ub = 32w + 2 (lane & 15)): global accesses are 8 bytes wide.
+//
+// A layer's input projection is not part of the recurrence: for a narrow input (the first
+// layer sees a_dim <= 4 features) it is formed in the kernel; otherwise the caller
+// computes it for all steps with one library GEMM and passes it in `gates`.
+#include <hip/hip_runtime.h>
+
+#include "../../include/kvae_kalman.h"
+#include "lstm_common.h"
+
+namespace kvae {
+
+constexpr int RH = 128;            // hidden size
+constexpr int RG4 = 4 * RH;
+constexpr int RLDA = RH + 2;       // LDS row stride of an h tile: rows 2 banks apart
+constexpr int RLDG = RG4 + 2;      // LDS row stride of a gate-gradient tile
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every
+// outstanding global store of the wavefront (its release fence covers global memory);
+// here each step leaves ~50 KB of streaming stores in flight per workgroup that nothing
+// in the workgroup reads back, and draining them at the barrier would cost more than the
+// step's matrix instructions.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct GateRows {                  // one lane's 4 rows x 2 units of the four gates
+    float2 v[4][4];                // [row][gate]
+};
+
+// grid = ceil(B/16), block = 256.  P > 0: the layer input x (T,B,P) with Wih (4H,P) and
+// bias (4H) = b_ih + b_hh is projected in the kernel; P == 0: gates (T,B,4H) holds the
+// input projection (bias included) on entry.  With store_gates the activated gates of
+// every step are written to `gates` (in place for P == 0).
+// FULL: all 16 rows of the workgroup's tile exist.  Then no access is predicated, the loop
+// body is one basic block and the compiler counts outstanding memory operations exactly;
+// with per-row predicates it waits for ALL of them (the previous step's ~50 KB of stores
+// included) before it touches the next step's prefetched inputs.
+template <int P, bool FULL, bool GATES>
+__device__ __forceinline__ void
+lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __restrict__ Wih,
+                     const float* __restrict__ bias, const float* __restrict__ WhhT, float* gates,
+                     float* __restrict__ h, float* __restrict__ c,
+                     const float* __restrict__ h_init, const float* __restrict__ c_init,
+                     float (&hbuf)[2][16 * RLDA]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
+    const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * cc;
+    const long BH = (long)B * RH, BG = (long)B * RG4;
+
+    // this wavefront's slice of the recurrent matrix: w[gate][hf][kb] multiplies
+    // h[., 4 kb + s] into the gate pre-activation of unit ub + hf
+    float w[4][2][32];
+#pragma unroll
+    for (int kb = 0; kb < 32; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float2 v =
+                *reinterpret_cast<const float2*>(WhhT + (long)(4 * kb + s) * RG4 + g * RH + ub);
+            w[g][0][kb] = v.x;
+            w[g][1][kb] = v.y;
+        }
+    }
+    float cst[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lr = 4 * s + i, row = r0 + lr;
+        cst[i][0] = cst[i][1] = 0.f;
+        if (c_init && (FULL || row < B)) {
+            const float2 v = *reinterpret_cast<const float2*>(c_init + (long)row * RH + ub);
+            cst[i][0] = v.x;
+            cst[i][1] = v.y;
+        }
+        // h of "step -1" (zero unless a state is carried in) goes where step 0 looks for it
+        float2 v = {0.f, 0.f};
+        if (h_init && (FULL || row < B))
+            v = *reinterpret_cast<const float2*>(h_init + (long)row * RH + ub);
+        *reinterpret_cast<float2*>(&hbuf[1][lr * RLDA + ub]) = v;
+    }
+    __syncthreads();
+
+    float wx[4][2][P > 0 ? P : 1], bs[4][2];
+    if (P > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bs[g][hf] = bias[g * RH + ub + hf];
+#pragma unroll
+                for (int q = 0; q < P; ++q) wx[g][hf][q] = Wih[(long)(g * RH + ub + hf) * P + q];
+            }
+        }
+    }
+    // input projection of a step for this lane's rows and units
+    auto load_gx = [&](int t, GateRows& gx) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            if (P > 0) {
+                float xv[P > 0 ? P : 1];
+#pragma unroll
+                for (int q = 0; q < P; ++q) xv[q] = (FULL || row < B) ? x[((long)t * B + row) * P + q] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a = bs[g][0], b = bs[g][1];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        a += xv[q] * wx[g][0][q];
+                        b += xv[q] * wx[g][1][q];
+                    }
+                    gx.v[i][g] = make_float2(a, b);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    gx.v[i][g] = make_float2(0.f, 0.f);
+                    if (FULL || row < B)
+                        gx.v[i][g] = load_streaming(gates + t * BG + (long)row * RG4 + g * RH + ub);
+                }
+            }
+        }
+    };
+
+    GateRows gx;
+    load_gx(0, gx);
+    for (int t = 0; t < T; ++t) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[g][0][i] = gx.v[i][g].x;
+                acc[g][1][i] = gx.v[i][g].y;
+            }
+        }
+        // the next step's input projection does not depend on the recurrence: its loads
+        // are in flight while this step's matrix instructions run
+        // (the last step loads its own inputs again rather than branch)
+        load_gx(t + 1 < T ? t + 1 : t, gx);
+        float2 res[4][6];
+        auto activate = [&](int i, int hf) {
+            const float a_i = sigmoidf_(acc[0][hf][i]), a_f = sigmoidf_(acc[1][hf][i]);
+            const float a_g = tanhf_(acc[2][hf][i]), a_o = sigmoidf_(acc[3][hf][i]);
+            const float cn = a_f * cst[i][hf] + a_i * a_g;
+            cst[i][hf] = cn;
+            const float hn = a_o * tanhf_(cn);
+            if (hf == 0) {
+                res[i][0].x = a_i; res[i][1].x = a_f; res[i][2].x = a_g; res[i][3].x = a_o;
+                res[i][4].x = hn; res[i][5].x = cn;
+            } else {
+                res[i][0].y = a_i; res[i][1].y = a_f; res[i][2].y = a_g; res[i][3].y = a_o;
+                res[i][4].y = hn; res[i][5].y = cn;
+            }
+        };
+        {
+            // all of the step's A operands are requested before the first matrix instruction
+            // (the compiler would otherwise sink each LDS read to its use and expose the
+            // read latency once per group of matrix instructions)
+            const float* a_row = hbuf[(t + 1) & 1] + cc * RLDA + s;
+            float a[32];
+#pragma unroll
+            for (int kb = 0; kb < 32; ++kb) a[kb] = a_row[4 * kb];
+            __builtin_amdgcn_sched_barrier(0);
+            // first unit of each pair
+#pragma unroll
+            for (int kb = 0; kb < 32; ++kb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb], w[g][0][kb], acc[g][0], 0, 0, 0);
+            }
+            // second unit, with the gate activations of the first unit between the groups
+#pragma unroll
+            for (int kb = 0; kb < 32; ++kb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb], w[g][1][kb], acc[g][1], 0, 0, 0);
+                if ((kb & 7) == 3) activate(kb >> 3, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) activate(i, 1);
+        float* h_tile = hbuf[t & 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lr = 4 * s + i, row = r0 + lr;
+            *reinterpret_cast<float2*>(h_tile + lr * RLDA + ub) = res[i][4];
+            if (FULL || row < B) {
+                const long o = (long)row * RH + ub;
+                store_streaming(h + t * BH + o, res[i][4]);
+                store_streaming(c + t * BH + o, res[i][5]);
+                if (GATES) {
+                    float* gr = gates + t * BG + (long)row * RG4 + ub;
+                    store_streaming(gr, res[i][0]);
+                    store_streaming(gr + RH, res[i][1]);
+                    store_streaming(gr + 2 * RH, res[i][2]);
+                    store_streaming(gr + 3 * RH, res[i][3]);
+                }
+            }
+        }
+        // orders this step's h writes before the next step's reads; the buffer written in
+        // step t+1 was last read in step t, before this barrier
+        lds_barrier();
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+lstm128_resident_forward_kernel(int T, int B, const float* __restrict__ x,
+                                const float* __restrict__ Wih, const float* __restrict__ bias,
+                                const float* __restrict__ WhhT,   // (H,4H)
+                                float* gates, float* __restrict__ h, float* __restrict__ c,
+                                const float* __restrict__ h_init,  // (B,H) or null
+                                const float* __restrict__ c_init, int store_gates) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][16 * RLDA];
+    const bool full = (int)blockIdx.x * 16 + 16 <= B;
+#define KVAE_FWD_BODY(F_, G_) \
+    lstm128_forward_body<P, F_, G_>(T, B, x, Wih, bias, WhhT, gates, h, c, h_init, c_init, hbuf)
+    if (store_gates) {
+        if (full) KVAE_FWD_BODY(true, true); else KVAE_FWD_BODY(false, true);
+    } else {
+        if (full) KVAE_FWD_BODY(true, false); else KVAE_FWD_BODY(false, false);
+    }
+#undef KVAE_FWD_BODY
+}
+
+// what the cell adjoint of one step reads from global memory for this lane's 4 rows x 2
+// units; independent of the recurrence, so loaded a step ahead
+struct CellRows {
+    float2 ig[4], fg[4], gg[4], og[4], cc[4], cp[4], gh[4];
+};
+
+// grid = ceil(B/16), block = 256.  g_h (T,B,H): gradient w.r.t. every h_t from above.
+// Whh (4H,H) as stored.  Outputs: dG (T,B,4H) gradient w.r.t. the gate pre-activations;
+// partial[blockIdx.x][ 4H | 4H | 4H*P ]: per-workgroup sums over (t, rows) of dG (twice:
+// bias_ih and bias_hh each get memory of their own) and, for P > 0, of dG^T x (the input
+// weight gradient); for P > 0 also dx (T,B,P) = dG Wih.
+template <int P, bool FULL>
+__device__ __forceinline__ void
+lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __restrict__ Wih,
+                      const float* __restrict__ gates, const float* __restrict__ cg,
+                      const float* __restrict__ c_init, const float* __restrict__ g_h,
+                      const float* __restrict__ Whh, float* __restrict__ dG,
+                      float* __restrict__ dx, float* __restrict__ partial,
+                      float (&tile)[2][16 * RLDG], float (&dx_part)[2][4][16][P > 0 ? P : 1]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
+    const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * cc;
+    const long BH = (long)B * RH, BG = (long)B * RG4;
+
+    // w[hf][kb] multiplies dG[., 4 kb + s] into dh of unit ub + hf
+    float w[2][128];
+#pragma unroll
+    for (int kb = 0; kb < 128; ++kb) {
+        const float2 v = *reinterpret_cast<const float2*>(Whh + (long)(4 * kb + s) * RH + ub);
+        w[0][kb] = v.x;
+        w[1][kb] = v.y;
+    }
+    float dc[4][2], sb[4][2], sw[4][2][P > 0 ? P : 1], wx[4][2][P > 0 ? P : 1];
+    f32x4 rec[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dc[i][0] = dc[i][1] = 0.f;
+        rec[0][i] = rec[1][i] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            sb[g][hf] = 0.f;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                sw[g][hf][q] = 0.f;
+                wx[g][hf][q] = Wih[(long)(g * RH + ub + hf) * P + q];
+            }
+        }
+    }
+    auto load_rows = [&](int t, CellRows& in) {
+        const float2 z = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * s + i;
+            in.ig[i] = in.fg[i] = in.gg[i] = in.og[i] = in.cc[i] = in.cp[i] = in.gh[i] = z;
+            if (FULL || row < B) {
+                const float* gr = gates + t * BG + (long)row * RG4 + ub;
+                in.ig[i] = load_streaming(gr);
+                in.fg[i] = load_streaming(gr + RH);
+                in.gg[i] = load_streaming(gr + 2 * RH);
+                in.og[i] = load_streaming(gr + 3 * RH);
+                const long o = (long)row * RH + ub;
+                in.cc[i] = load_streaming(cg + t * BH + o);
+                if (t > 0) {
+                    in.cp[i] = load_streaming(cg + (t - 1) * BH + o);
+                } else if (c_init) {
+                    in.cp[i] = *reinterpret_cast<const float2*>(c_init + o);
+                }
+                in.gh[i] = load_streaming(g_h + t * BH + o);
+            }
+        }
+    };
+
+    CellRows in;
+    load_rows(T - 1, in);
+    for (int t = T - 1; t >= 0; --t) {
+        float* g_tile = tile[t & 1];
+        float2 dgs[4][4];   // this step's gate gradients, stored during the matrix loop
+        float xv[4][P > 0 ? P : 1];
+        if (P > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = r0 + 4 * s + i;
+#pragma unroll
+                for (int q = 0; q < P; ++q) xv[i][q] = (FULL || row < B) ? x[((long)t * B + row) * P + q] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lr = 4 * s + i, row = r0 + lr;
+            const float dh0 = rec[0][i] + in.gh[i].x, dh1 = rec[1][i] + in.gh[i].y;
+            float2 di, df, dg, dout;
+            {
+                const float tc = tanhf_(in.cc[i].x);
+                const float dct = dh0 * in.og[i].x * (1.f - tc * tc) + dc[i][0];
+                di.x = dct * in.gg[i].x * in.ig[i].x * (1.f - in.ig[i].x);
+                df.x = dct * in.cp[i].x * in.fg[i].x * (1.f - in.fg[i].x);
+                dg.x = dct * in.ig[i].x * (1.f - in.gg[i].x * in.gg[i].x);
+                dout.x = dh0 * tc * in.og[i].x * (1.f - in.og[i].x);
+                dc[i][0] = dct * in.fg[i].x;
+            }
+            {
+                const float tc = tanhf_(in.cc[i].y);
+                const float dct = dh1 * in.og[i].y * (1.f - tc * tc) + dc[i][1];
+                di.y = dct * in.gg[i].y * in.ig[i].y * (1.f - in.ig[i].y);
+                df.y = dct * in.cp[i].y * in.fg[i].y * (1.f - in.fg[i].y);
+                dg.y = dct * in.ig[i].y * (1.f - in.gg[i].y * in.gg[i].y);
+                dout.y = dh1 * tc * in.og[i].y * (1.f - in.og[i].y);
+                dc[i][1] = dct * in.fg[i].y;
+            }
+            dgs[i][0] = di;
+            dgs[i][1] = df;
+            dgs[i][2] = dg;
+            dgs[i][3] = dout;
+            float* tl = g_tile + lr * RLDG + ub;
+            *reinterpret_cast<float2*>(tl) = di;
+            *reinterpret_cast<float2*>(tl + RH) = df;
+            *reinterpret_cast<float2*>(tl + 2 * RH) = dg;
+            *reinterpret_cast<float2*>(tl + 3 * RH) = dout;
+            const float2 dgt[4] = {di, df, dg, dout};
+            float dxp[P > 0 ? P : 1];
+#pragma unroll
+            for (int q = 0; q < P; ++q) dxp[q] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sb[g][0] += dgt[g].x;
+                sb[g][1] += dgt[g].y;
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    sw[g][0][q] += dgt[g].x * xv[i][q];
+                    sw[g][1][q] += dgt[g].y * xv[i][q];
+                    dxp[q] += dgt[g].x * wx[g][0][q] + dgt[g].y * wx[g][1][q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const float v = row_sum16(dxp[q]);
+                if (cc == 0) dx_part[t & 1][wave][lr][q] = v;
+            }
+        }
+        // inputs of the next step, in flight during the matrix instructions below
+        if (t > 0) load_rows(t - 1, in);
+        lds_barrier();
+        if (P > 0 && threadIdx.x < 16 * P) {
+            const int lr = threadIdx.x / (P > 0 ? P : 1), q = threadIdx.x % (P > 0 ? P : 1);
+            if (FULL || r0 + lr < B)
+                dx[((long)t * B + r0 + lr) * P + q] =
+                    dx_part[t & 1][0][lr][q] + dx_part[t & 1][1][lr][q] +
+                    dx_part[t & 1][2][lr][q] + dx_part[t & 1][3][lr][q];
+        }
+        // dh_{t-1} (recurrent part) = dG_t Whh
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rec[0][i] = rec[1][i] = 0.f;
+        // the step's gate gradients go to global memory one store per group of matrix
+        // instructions (issued together, every compute unit would write at the same moment
+        // and wait for memory while the matrix pipe idles)
+        auto store_dg = [&](int idx) {
+            const int i = idx >> 2, g = idx & 3;
+            if (FULL || r0 + 4 * s + i < B) store_streaming(dG + t * BG + (long)(r0 + 4 * s + i) * RG4 + g * RH + ub, dgs[i][g]);
+        };
+        if (t > 0) {
+            const float* a_row = g_tile + cc * RLDG + s;
+#pragma unroll
+            for (int kb = 0; kb < 128; ++kb) {
+                const float a = a_row[4 * kb];
+                rec[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[0][kb], rec[0], 0, 0, 0);
+                rec[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[1][kb], rec[1], 0, 0, 0);
+                if ((kb & 7) == 7) {
+                    store_dg(kb >> 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) store_dg(idx);
+        }
+        // tile[t & 1] is rewritten in step t-2, after the barrier of step t-1 that every
+        // wavefront reaches only after its reads above
+    }
+    // sum the per-lane column accumulators over the four row groups (lane bits 4, 5)
+    float* part = partial + (long)blockIdx.x * (RG4 * (2 + P));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int col = g * RH + ub + hf;
+            float a = sb[g][hf];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            if (s == 0) {
+                part[col] = a;
+                part[RG4 + col] = a;
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                float v = sw[g][hf][q];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (s == 0) part[2 * RG4 + (long)col * P + q] = v;
+            }
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+lstm128_resident_backward_kernel(int T, int B, const float* __restrict__ x,
+                                 const float* __restrict__ Wih, const float* __restrict__ gates,
+                                 const float* __restrict__ cg, const float* __restrict__ c_init,
+                                 const float* __restrict__ g_h, const float* __restrict__ Whh,
+                                 float* __restrict__ dG, float* __restrict__ dx,
+                                 float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * RLDG];
+    __shared__ float dx_part[2][4][16][P > 0 ? P : 1];
+    // (one body for full and ragged tiles: a second, unpredicated instance costs registers
+    // the resident matrix needs)
+    lstm128_backward_body<P, false>(T, B, x, Wih, gates, cg, c_init, g_h, Whh, dG, dx, partial,
+                                    tile, dx_part);
+}
+
+}  // namespace kvae
+
+using namespace kvae;
+
+extern "C" {
+
+int kvae_lstm128_blocks(int B) { return B < 1 ? 0 : (B + 15) / 16; }
+
+int kvae_lstm128_forward(int T, int B, int P, const void* x, const void* Wih, const void* bias,
+                         const void* WhhT, void* gates, void* h, void* c, const void* h_init,
+                         const void* c_init, int store_gates, void* stream) {
+    if (T < 1 || B < 1 || !WhhT || !h || !c || (h_init == nullptr) != (c_init == nullptr) ||
+        (P > 0 && (!x || !Wih || !bias)) || (P == 0 && !gates) || (store_gates && !gates))
+        return KVAE_E_BADARG;
+    const dim3 grid((B + 15) / 16);
+#define KVAE_R128F(P_)                                                                           \
+    hipLaunchKernelGGL(lstm128_resident_forward_kernel<P_>, grid, dim3(256), 0,                  \
+                       (hipStream_t)stream, T, B, (const float*)x, (const float*)Wih,            \
+                       (const float*)bias, (const float*)WhhT, (float*)gates, (float*)h,         \
+                       (float*)c, (const float*)h_init, (const float*)c_init, store_gates)
+    switch (P) {
+        case 0: KVAE_R128F(0); break;
+        case 1: KVAE_R128F(1); break;
+        case 2: KVAE_R128F(2); break;
+        case 3: KVAE_R128F(3); break;
+        case 4: KVAE_R128F(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_R128F
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+int kvae_lstm128_backward(int T, int B, int P, const void* x, const void* Wih, const void* gates,
+                          const void* c, const void* c_init, const void* g_h, const void* Whh,
+                          void* dG, void* dx, void* partial, void* stream) {
+    if (T < 1 || B < 1 || !gates || !c || !g_h || !Whh || !dG || !partial ||
+        (P > 0 && (!x || !Wih || !dx)))
+        return KVAE_E_BADARG;
+    const dim3 grid((B + 15) / 16);
+#define KVAE_R128B(P_)                                                                           \
+    hipLaunchKernelGGL(lstm128_resident_backward_kernel<P_>, grid, dim3(256), 0,                 \
+                       (hipStream_t)stream, T, B, (const float*)x, (const float*)Wih,            \
+                       (const float*)gates, (const float*)c, (const float*)c_init,               \
+                       (const float*)g_h, (const float*)Whh, (float*)dG, (float*)dx,             \
+                       (float*)partial)
+    switch (P) {
+        case 0: KVAE_R128B(0); break;
+        case 1: KVAE_R128B(1); break;
+        case 2: KVAE_R128B(2); break;
+        case 3: KVAE_R128B(3); break;
+        case 4: KVAE_R128B(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_R128B
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+}  // extern "C"

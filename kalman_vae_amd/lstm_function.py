@@ -16,6 +16,9 @@ from . import _capi as capi
 
 
 PERSISTENT = True  # use the one-launch kernels when the shape allows it
+# two-layer H=128 network: one launch per LAYER with the recurrent matrix resident in
+# registers (False: one launch for both layers, weights streamed from L2 every step)
+RESIDENT = True
 
 
 def supported(x, hidden_dim):
@@ -220,6 +223,77 @@ class FusedLSTM2Function(torch.autograd.Function):
         return dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b
 
 
+class ResidentLSTM2Function(torch.autograd.Function):
+    """Two layers, hidden size 128, layer-0 input dimension <= 4, one launch per layer and
+    direction with the layer's recurrent matrix resident in registers
+    (kvae_lstm128_forward / _backward).  Layer 1's input product over all steps and the
+    product that carries the gradient from layer 1 to layer 0 are time-batched library
+    GEMMs; so are the three recurrent / input weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+        lib = capi.load()
+        T, B, P = x.shape
+        H = 128
+        x = x.contiguous()
+        new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
+        gates0, h0, c0 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+        gates1, h1, c1 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+        whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1,
+                                                      b_hh1)
+        wih0 = w_ih0.contiguous()
+        stream = capi.current_stream_ptr()
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
+            gates0.data_ptr(), h0.data_ptr(), c0.data_ptr(), None, None, 1, stream))
+        # layer 1's input projection of all steps: (T*B,128) x (128,512) + bias
+        torch.addmm(b1, h0.view(T * B, H), wih1t, out=gates1.view(T * B, 4 * H))
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
+            c1.data_ptr(), None, None, 1, stream))
+        ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
+        ctx.mark_non_differentiable(h0, c0, c1)
+        ctx.set_materialize_grads(False)
+        return h1, h0, c0, c1
+
+    @staticmethod
+    def backward(ctx, g_h1, _dh0, _dc0, _dc1):
+        lib = capi.load()
+        x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
+        T, B, P = x.shape
+        H = 128
+        g_h1 = g_h1.contiguous()
+        dG0, dG1 = torch.empty_like(gates0), torch.empty_like(gates1)
+        dx = torch.empty_like(x)
+        blocks = lib.kvae_lstm128_blocks(B)
+        part1 = torch.empty(blocks, 4 * H * 2, dtype=x.dtype, device=x.device)
+        part0 = torch.empty(blocks, 4 * H * (2 + P), dtype=x.dtype, device=x.device)
+        wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
+        stream = capi.current_stream_ptr()
+        capi.check(lib.kvae_lstm128_backward(
+            T, B, 0, None, None, gates1.data_ptr(), c1.data_ptr(), None, g_h1.data_ptr(),
+            whh1.data_ptr(), dG1.data_ptr(), None, part1.data_ptr(), stream))
+        d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
+        # gradient w.r.t. layer 0's h through layer 1's input product
+        g_h0 = torch.mm(d1, wih1).view(T, B, H)
+        capi.check(lib.kvae_lstm128_backward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
+            g_h0.data_ptr(), whh0.data_ptr(), dG0.data_ptr(), dx.data_ptr(), part0.data_ptr(),
+            stream))
+        s1, s0 = capi.column_sum(part1), capi.column_sum(part0)
+        db1, db1b = s1[:4 * H], s1[4 * H:]
+        db0, db0b = s0[:4 * H], s0[4 * H:8 * H]
+        dw_ih0 = s0[8 * H:].view(4 * H, P)
+        zero = lambda w: torch.zeros_like(w)
+        if T > 1:
+            dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
+                (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),
+                (d1[B:], h1[:-1].reshape(-1, H))])
+        else:
+            dw_hh0, dw_ih1, dw_hh1 = zero(w_hh0), _splitk_tn(d1, h0.reshape(T * B, H)), zero(w_hh1)
+        return dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b
+
+
 class SoftmaxHeadFunction(torch.autograd.Function):
     """softmax(h @ W^T + b) over the last axis: h (..., H), W (K, H), b (K).  With
     lead = True and h (T,B,H) the result is (T+1,B,K) whose first step is the
@@ -367,7 +441,8 @@ def fused_lstm(x, lstm):
         params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
                    getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
     if lstm.num_layers == 2 and lstm.hidden_size == 128 and x.shape[2] <= 4 and PERSISTENT:
-        out, h0, c0, c1 = FusedLSTM2Function.apply(x, *params)
+        fn = ResidentLSTM2Function if RESIDENT else FusedLSTM2Function
+        out, h0, c0, c1 = fn.apply(x, *params)
         return out, LastState((h0[-1], out.detach()[-1]), (c0[-1], c1[-1]))
     out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
     return out, (h_n, c_n)

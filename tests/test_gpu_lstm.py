@@ -10,7 +10,7 @@ from golden_util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("persistent", [16, 32, 0])
+@pytest.mark.parametrize("persistent", ["resident", 16, 32, 0])
 @pytest.mark.parametrize("T,B,p,H,L", [(20, 70, 2, 128, 2), (5, 33, 3, 32, 1), (7, 64, 2, 64, 3),
                                        (1, 40, 2, 128, 2), (3, 1, 16, 128, 2), (9, 32, 4, 128, 2),
                                        (4, 200, 1, 128, 2)])
@@ -19,8 +19,10 @@ def test_fused_lstm_matches_torch(T, B, p, H, L, persistent, monkeypatch):
     from kalman_vae_amd.lstm_function import fused_lstm
     # persistent: tile rows of the one-launch two-layer kernels (both forms are
     # forced in turn; the library picks by batch size otherwise), 0 = per-step kernels
+    # "resident": one launch per layer, recurrent matrix in registers (the default)
     monkeypatch.setattr(lf, "PERSISTENT", bool(persistent))
-    if persistent:
+    monkeypatch.setattr(lf, "RESIDENT", persistent == "resident")
+    if persistent and persistent != "resident":
         monkeypatch.setenv("KVAE_LSTM_TILE_ROWS", str(persistent))
     torch.manual_seed(T * 100 + B)
     dev = torch.device("cuda:0")
@@ -99,3 +101,64 @@ def test_weight_model_stepwise_inference_on_hip_equals_torch(B, rows, monkeypatc
         h_ref = net.hidden
     assert rel_err(hip, ref) < 1e-5
     assert rel_err(h_hip[0], h_ref[0]) < 1e-5 and rel_err(h_hip[1], h_ref[1]) < 1e-5
+
+
+@pytest.mark.parametrize("T,B,P", [(6, 37, 0), (4, 16, 2), (1, 5, 3), (3, 100, 4)])
+def test_resident_layer_with_carried_state_matches_torch(T, B, P):
+    """kvae_lstm128_forward / _backward through the C ABI on ONE layer that starts from a
+    given (h, c): outputs, dG-derived gradients, dx and the bias / input-weight sums
+    against torch.nn.LSTM (fp32 both sides)."""
+    import ctypes as C
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(T * 10 + B)
+    dev = torch.device("cuda:0")
+    H = 128
+    in_dim = P if P > 0 else H
+    lstm = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev)
+    x = torch.randn(T, B, in_dim, device=dev, requires_grad=True)
+    h_in = (0.5 * torch.randn(1, B, H, device=dev)).requires_grad_(False)
+    c_in = 0.5 * torch.randn(1, B, H, device=dev)
+    wgt = torch.randn(T, B, H, device=dev)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref, (hn, cn) = lstm(x, (h_in, c_in))
+        gref = torch.autograd.grad((ref * wgt).sum(), [x] + list(lstm.parameters()))
+    w_ih, w_hh = lstm.weight_ih_l0.detach(), lstm.weight_hh_l0.detach()
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().contiguous()
+    whht = w_hh.t().contiguous()
+    new = lambda *s: torch.full(s, float("nan"), device=dev)
+    gates, h, c = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+    st = torch.cuda.current_stream().cuda_stream
+    xd = x.detach().contiguous()
+    if P == 0:
+        gates.copy_(torch.addmm(bias, xd.view(T * B, H), w_ih.t()).view(T, B, 4 * H))
+        rc = lib.kvae_lstm128_forward(T, B, 0, None, None, None, whht.data_ptr(), gates.data_ptr(),
+                                      h.data_ptr(), c.data_ptr(), h_in[0].contiguous().data_ptr(),
+                                      c_in[0].contiguous().data_ptr(), 1, st)
+    else:
+        rc = lib.kvae_lstm128_forward(T, B, P, xd.data_ptr(), w_ih.contiguous().data_ptr(),
+                                      bias.data_ptr(), whht.data_ptr(), gates.data_ptr(),
+                                      h.data_ptr(), c.data_ptr(), h_in[0].contiguous().data_ptr(),
+                                      c_in[0].contiguous().data_ptr(), 1, st)
+    assert rc == 0
+    assert rel_err(h, ref) < 1e-5
+    assert rel_err(h[-1], hn[0]) < 1e-5 and rel_err(c[-1], cn[0]) < 1e-5
+    dG, dx = new(T, B, 4 * H), new(T, B, max(P, 1))
+    part = new(lib.kvae_lstm128_blocks(B), 4 * H * (2 + P))
+    rc = lib.kvae_lstm128_backward(T, B, P, xd.data_ptr() if P else None,
+                                   w_ih.contiguous().data_ptr() if P else None, gates.data_ptr(),
+                                   c.data_ptr(), c_in[0].contiguous().data_ptr(),
+                                   wgt.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                   dG.data_ptr(), dx.data_ptr() if P else None, part.data_ptr(), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    sums = part.sum(0)
+    d2 = dG.view(T * B, 4 * H)
+    h_prev = torch.cat([h_in, h[:-1]]).view(T * B, H)
+    got = {"x": (d2 @ w_ih).view(T, B, -1) if P == 0 else dx,
+           "weight_ih_l0": d2.t() @ xd.view(T * B, -1) if P == 0 else sums[8 * H:].view(4 * H, P),
+           "weight_hh_l0": d2.t() @ h_prev, "bias_ih_l0": sums[:4 * H],
+           "bias_hh_l0": sums[4 * H:8 * H]}
+    names = ["x"] + [n for n, _ in lstm.named_parameters()]
+    bad = [(n, rel_err(got[n], g)) for n, g in zip(names, gref) if not rel_err(got[n], g) < 1e-4]
+    assert not bad, bad

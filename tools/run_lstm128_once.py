@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Launch each register-resident LSTM layer kernel a few times (for rocprofv3 counter runs)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kalman_vae_amd import _capi as capi   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T, P, H = 20, 2, 128
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+lib = capi.load()
+new = lambda *s: torch.randn(*s, device=dev)
+x, wih, bias = new(T, B, P), 0.1 * new(4 * H, P), 0.1 * new(4 * H)
+whht, whh = 0.08 * new(H, 4 * H), 0.08 * new(4 * H, H)
+gates, h, c = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+gx = new(T, B, 4 * H)
+g_h = 1e-3 * new(T, B, H)
+dG, dx = new(T, B, 4 * H), new(T, B, P)
+part = new(lib.kvae_lstm128_blocks(B), 4 * H * (2 + P))
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    lib.kvae_lstm128_forward(T, B, P, x.data_ptr(), wih.data_ptr(), bias.data_ptr(),
+                             whht.data_ptr(), gates.data_ptr(), h.data_ptr(), c.data_ptr(), None,
+                             None, 1, st)
+    gx2 = gx.clone()
+    lib.kvae_lstm128_forward(T, B, 0, None, None, None, whht.data_ptr(), gx2.data_ptr(),
+                             h.data_ptr(), c.data_ptr(), None, None, 1, st)
+    lib.kvae_lstm128_backward(T, B, P, x.data_ptr(), wih.data_ptr(), gates.data_ptr(), c.data_ptr(),
+                              None, g_h.data_ptr(), whh.data_ptr(), dG.data_ptr(), dx.data_ptr(),
+                              part.data_ptr(), st)
+    lib.kvae_lstm128_backward(T, B, 0, None, None, gates.data_ptr(), c.data_ptr(), None,
+                              g_h.data_ptr(), whh.data_ptr(), dG.data_ptr(), None, part.data_ptr(),
+                              st)
+torch.cuda.synchronize()
