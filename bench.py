@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""Benchmark of the Kalman filter + RTS smoother + Kalman-ELBO hot path,
-forward and backward, on MI355X.
+"""Benchmark of the Kalman filter + RTS smoother + Kalman-ELBO hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5]
 
-One "step" = one forward+backward pass of the path over one batch of synthetic
-bouncing-ball-shaped sequences: weight network -> mixing weights -> filter ->
-smoother -> ELBO terms -> aggregate -> backward through all of it (plus, for
-N > 1, one flat-bucket RCCL all-reduce of the parameter gradients).  Inputs are
-resident in HBM before the timed region.  Per-GPU work is fixed as N grows
-(weak scaling): every rank processes its own B sequences.
+--config selects one of the five benchmark configurations (default c2, the one the
+headline metric is quoted on):
+  c1  training step, T=20, a_dim=2, z_dim=4, K=3, 32 sequences (the CPU reference's size)
+  c2  the same shapes, 4096 sequences per GPU
+  c3  masked imputation (filter + smoother, forward only, observation mask with keep
+      probability 0.7), 1 048 576 sequences split over the GPUs, no collective
+  c4  long / large state: T=1000, a_dim=16, z_dim=32, K=8, 1024 sequences per GPU
+  c5  full Kalman-VAE training step on 64x64 frames, 128 sequences per GPU, Adam
 
-Rank 0 prints ONE JSON line.  `value` = sequence-steps/s of the whole job
-(N * T * B * steps / max-over-ranks time).  Additional objects:
-  roofline      dominant kernel: algorithmic bytes / measured duration vs HBM peak
-  cpu_baseline  the oracle (a per-step PyTorch restatement of the reference
-                algorithm) timed on this machine's host cores on the same workload
-  kernels       per-kernel average durations (HIP events) and rates
+One "step" of c1/c2/c4 = one forward+backward pass of the path over one batch of
+synthetic bouncing-ball-shaped sequences: weight network -> mixing weights -> filter ->
+smoother -> ELBO terms -> aggregate -> backward through all of it (plus, for N > 1, one
+flat-bucket RCCL all-reduce of the parameter gradients).  Inputs are resident in HBM before
+the timed region.  Per-GPU work is fixed as N grows (weak scaling), except c3 whose total
+is fixed (strong scaling).
+
+Rank 0 prints ONE JSON line.  `value` = sequence-steps/s of the whole job.  Additional
+objects:
+  roofline         the kernel that takes most of the step: achieved rate against its roof
+  kalman_roofline  the longest kernel of the Kalman path itself, same form
+  cpu_baseline     the oracle (a per-step PyTorch restatement of the reference algorithm)
+                   timed on this machine's host cores
+  kernels          per-kernel average durations (HIP events) and rates
 """
 import argparse
 import ctypes as C
@@ -98,10 +107,25 @@ def kernel_bytes(n, p, K, el):
 MFMA_FP32_PEAK_TF = 157.3   # dense fp32 matrix-core peak of MI355X
 
 
+def _timed(fn, iters):
+    """Average seconds per call of fn (HIP events on the stream fn launches on)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
 def time_lstm_kernels(ssm, a, iters=20):
-    """HIP-event durations of the two persistent LSTM kernels of the weight network
-    (the step's longest kernels) at the bench shape, launched through the C ABI on
-    the current stream; None when the network is not the default two-layer H=128 LSTM."""
+    """HIP-event durations of the weight network's recurrent kernels (one launch per layer
+    and direction, recurrent matrix resident in registers) at the bench shape, launched
+    through the C ABI on the current stream; None when the network is not the default
+    two-layer H=128 LSTM."""
     from kalman_vae_amd import _capi as capi
     from kalman_vae_amd import lstm_function as LF
     net = ssm.weight_model
@@ -113,48 +137,109 @@ def time_lstm_kernels(ssm, a, iters=20):
     H = 128
     dev = a.device
     x = a.detach().contiguous()
-    w = lambda nme: getattr(lstm, nme).detach()
-    whh0t, wih1t, whh1t, b0, b1 = LF._lstm2_operands(
-        w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
-        w("bias_ih_l1"), w("bias_hh_l1"))
+    w = lambda nme: getattr(lstm, nme).detach().contiguous()
     new = lambda *s: torch.empty(*s, dtype=x.dtype, device=dev)
-    g0, h0, c0, g1, h1, c1 = (new(T, B, 4 * H), new(T, B, H), new(T, B, H), new(T, B, 4 * H),
-                              new(T, B, H), new(T, B, H))
-    dG0, dG1, dx = torch.empty_like(g0), torch.empty_like(g1), torch.empty_like(x)
+    gates, h, c = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+    gx = torch.randn(T, B, 4 * H, dtype=x.dtype, device=dev)
+    dG, dx = new(T, B, 4 * H), new(T, B, P)
     gh = torch.randn(T, B, H, dtype=x.dtype, device=dev) * 1e-3
-    part = new(lib.kvae_lstm2_backward_blocks(B), 4 * H * (4 + P))
-    wih0 = w("weight_ih_l0").contiguous()
+    part = new(lib.kvae_lstm128_blocks(B), 4 * H * (2 + P))
+    wih0, whh0, whh1 = w("weight_ih_l0"), w("weight_hh_l0"), w("weight_hh_l1")
+    whh0t, whh1t = whh0.t().contiguous(), whh1.t().contiguous()
+    b0 = (w("bias_ih_l0") + w("bias_hh_l0")).contiguous()
     st = capi.current_stream_ptr()
-
-    def fwd():
-        capi.check(lib.kvae_lstm2_forward(
+    calls = {
+        "lstm_layer0_forward": lambda: capi.check(lib.kvae_lstm128_forward(
             T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
-            wih1t.data_ptr(), whh1t.data_ptr(), b1.data_ptr(), g0.data_ptr(), h0.data_ptr(),
-            c0.data_ptr(), g1.data_ptr(), h1.data_ptr(), c1.data_ptr(), None, None, st))
-
-    def bwd():
-        capi.check(lib.kvae_lstm2_backward(
-            T, B, P, gh.data_ptr(), x.data_ptr(), g0.data_ptr(), c0.data_ptr(), g1.data_ptr(),
-            c1.data_ptr(), wih0.data_ptr(), w("weight_hh_l0").contiguous().data_ptr(),
-            w("weight_ih_l1").contiguous().data_ptr(), w("weight_hh_l1").contiguous().data_ptr(),
-            dG0.data_ptr(), dG1.data_ptr(), dx.data_ptr(), part.data_ptr(), st))
-
-    flops = 2.0 * T * B * 4 * H * 3 * H     # one recurrent product per layer + layer 1's input product
+            gates.data_ptr(), h.data_ptr(), c.data_ptr(), None, None, 1, st)),
+        "lstm_layer1_forward": lambda: capi.check(lib.kvae_lstm128_forward(
+            T, B, 0, None, None, None, whh1t.data_ptr(), gx.data_ptr(), h.data_ptr(), c.data_ptr(),
+            None, None, 1, st)),
+        "lstm_layer1_backward": lambda: capi.check(lib.kvae_lstm128_backward(
+            T, B, 0, None, None, gates.data_ptr(), c.data_ptr(), None, gh.data_ptr(),
+            whh1.data_ptr(), dG.data_ptr(), None, part.data_ptr(), st)),
+        "lstm_layer0_backward": lambda: capi.check(lib.kvae_lstm128_backward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), gates.data_ptr(), c.data_ptr(), None,
+            gh.data_ptr(), whh0.data_ptr(), dG.data_ptr(), dx.data_ptr(), part.data_ptr(), st)),
+    }
+    kernel_of = {"lstm_layer0_forward": f"lstm128_resident_forward_kernel<{P}>",
+                 "lstm_layer1_forward": "lstm128_resident_forward_kernel<0>",
+                 "lstm_layer1_backward": "lstm128_resident_backward_kernel<0>",
+                 "lstm_layer0_backward": f"lstm128_resident_backward_kernel<{P}>"}
+    flops = 2.0 * T * B * 4 * H * H     # the recurrent product of one layer
+    # compulsory HBM bytes of a launch: activated gates, h, c written (forward) / read with
+    # the upstream gradient and c_{t-1}, gate gradients written (backward)
+    by = {"lstm_layer0_forward": 4.0 * T * B * (6 * H + P),
+          "lstm_layer1_forward": 4.0 * T * B * (6 * H + 4 * H),
+          "lstm_layer1_backward": 4.0 * T * B * (7 * H + 4 * H),
+          "lstm_layer0_backward": 4.0 * T * B * (7 * H + 4 * H + 2 * P)}
     out = {}
-    for name, fn in (("lstm_forward", fwd), ("lstm_backward", bwd)):
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        sec = e0.elapsed_time(e1) / iters * 1e-3
-        out[name] = {"us": sec * 1e6, "bound": "mfma", "achieved": flops / sec / 1e12,
-                     "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": flops / sec / 1e12 / MFMA_FP32_PEAK_TF, "flops_per_launch": flops}
+    for name, fn in calls.items():
+        sec = _timed(fn, iters)
+        out[name] = {"kernel": kernel_of[name], "us": sec * 1e6, "bound": "mfma",
+                     "achieved": flops / sec / 1e12, "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / sec / 1e12 / MFMA_FP32_PEAK_TF, "flops_per_launch": flops,
+                     "hbm_bytes_per_launch": by[name], "hbm_GBps": by[name] / sec / 1e9}
     return out
+
+
+def time_fused_kernels(ssm, a, burn_in, iters=30):
+    """HIP-event durations of the fused objective's two launches (kvae_kalman_loss_forward /
+    _backward: filter -> smoother -> ELBO terms and their adjoint) through the C ABI on the
+    tensors of the bench, with the weight network's real mixing weights."""
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd import functions as F
+    lib = capi.load()
+    dev, dt = a.device, a.dtype
+    T, B, p = a.shape
+    n, K = ssm.z_dim, ssm.K
+    if not lib.kvae_loss_supported(n, p, K, capi.dtype_code(dt)):
+        return None
+    with torch.no_grad():
+        ssm.weight_model.clear_hidden_state()
+        alpha = ssm.weight_model(a, lead=True).contiguous()
+        A_K, C_K = ssm.mat_A_K.contiguous(), ssm.mat_C_K.contiguous()
+        Q, R = ssm.mat_Q.contiguous(), ssm.mat_R.contiguous()
+        m0, P0 = ssm.initial_state_mean, ssm.initial_state_covariance
+    new = lambda *s: torch.empty(s, dtype=dt, device=dev)
+    dims = capi.Dims(T, B, n, p, K, capi.dtype_code(dt), 1, burn_in)
+    saved = torch.empty(lib.kvae_loss_saved_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+    eps, out = torch.randn(T, B, n, dtype=dt, device=dev), new(4)
+    lf = capi.fill(capi.LossFwd(), a=a.detach(), alpha=alpha, mask=None, A_K=A_K, C_K=C_K, Q=Q,
+                   R=R, m0=m0, P0=P0, eps=eps, saved=saved, terms=None, out=out,
+                   status=F.status_word(dev))
+    c = 1.0 / (T * B)
+    lf.w_obs, lf.w_trans, lf.w_post = c, c, -c
+    d = dict(a=new(T, B, p), alpha=new(T + 1, B, K), A_K=new(K, n, n), C_K=new(K, p, n),
+             Q=new(n, n), R=new(p, p))
+    scale = torch.full((1,), -1.0, dtype=dt, device=dev)
+    lb = capi.LossBwd()
+    lb.fwd = lf
+    capi.fill(lb, g_scale=scale, g_scale_stride=0, d_a=d["a"], d_alpha=d["alpha"], d_A_K=d["A_K"],
+              d_C_K=d["C_K"], d_Q=d["Q"], d_R=d["R"], d_m0=None, d_P0=None)
+    nf = lib.kvae_workspace_bytes(C.byref(dims), capi.OP_LOSS_FWD)
+    nb = lib.kvae_workspace_bytes(C.byref(dims), capi.OP_LOSS_BWD)
+    ws = torch.empty(max(nf, nb, 8), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    tf = _timed(lambda: capi.check(lib.kvae_kalman_loss_forward(
+        C.byref(dims), C.byref(lf), ws.data_ptr(), nf, stream)), iters)
+    tb = _timed(lambda: capi.check(lib.kvae_kalman_loss_backward(
+        C.byref(dims), C.byref(lb), ws.data_ptr(), nb, stream)), iters)
+    return {"loss_forward": tf, "loss_backward": tb}
+
+
+def fused_bytes(n, p, K, el):
+    """Compulsory global-memory bytes per sequence-step of the fused objective's two
+    launches: inputs (a, alpha, eps) read, the state handed from the forward to the
+    backward pass (filtered, predicted and smoothed means and covariances) written once
+    and read once, the gradients handed from the backward pass's first sweep to its second
+    written and read, d_a and d_alpha written."""
+    v, c = n, n * n
+    inputs = p + K + n
+    saved = 3 * v + 3 * c
+    bars = 2 * v + 2 * c
+    return {"loss_forward": el * (inputs + saved + (2 * v + 2 * c)),   # + the filter state re-read
+            "loss_backward": el * (inputs + saved + (2 * v + 2 * c) + 2 * bars + 2 * (p + K))}
 
 
 def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
@@ -248,10 +333,22 @@ def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
     return out
 
 
-def cpu_baseline(T, B, net, burn_in, n=4, p=2, K=3, budget_s=20.0):
-    """The oracle (per-step PyTorch ops, autograd backward) on the host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_time_objective(T, B, net, burn_in, n, p, K, threads, budget_s, max_iters, min_iters=3):
+    """Median seconds of one forward+backward of the oracle's Kalman objective."""
     from kalman_vae_amd import StateSpaceModel
     from oracle import kalman_oracle as O
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     ssm = StateSpaceModel(a_dim=p, z_dim=n, K=K, dynamics_parameter_network=net)
     ssm.mat_Q = torch.eye(n)
@@ -275,44 +372,55 @@ def cpu_baseline(T, B, net, burn_in, n=4, p=2, K=3, budget_s=20.0):
     step()  # warm-up
     times = []
     t_start = time.perf_counter()
-    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
+    while len(times) < min_iters or (time.perf_counter() - t_start < budget_s
+                                     and len(times) < max_iters):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    return {"value": T * B / med, "unit": "sequence-steps/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{len(times)} fwd+bwd iterations of T={T} B={B} (median {med*1e3:.1f} ms), "
-                      f"oracle/kalman_oracle.py with the {net} weight network, torch "
-                      f"{torch.__version__} CPU, {os.cpu_count()} logical CPUs visible"}
+    return sorted(times)[len(times) // 2], len(times)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4096, help="sequences per GPU")
-    ap.add_argument("--seq-len", type=int, default=20)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "mlp"])
-    ap.add_argument("--burn-in", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--state-dim", type=int, default=4)
-    ap.add_argument("--obs-dim", type=int, default=2)
-    ap.add_argument("--bases", type=int, default=3)
-    ap.add_argument("--kernels-only", action="store_true",
-                    help="time only the six HIP kernels with synthetic mixing weights "
-                         "(softmax of N(0,1)); no PyTorch weight network, no autograd glue")
-    ap.add_argument("--kernel-iters", type=int, default=30)
-    ap.add_argument("--separate-kernels", action="store_true",
-                    help="run filter, smoother and ELBO terms as six separate kernels with all "
-                         "their tensors materialised (the drop-in API's path) instead of the "
-                         "fused objective")
-    ap.add_argument("--no-hip-graph", action="store_true",
-                    help="run the step eagerly instead of replaying it as one HIP graph")
-    args = ap.parse_args()
+def cpu_baseline(T, B, net, burn_in, n=4, p=2, K=3, budget_s=12.0):
+    """The oracle (per-step PyTorch ops, autograd backward) on the host cores: the
+    workload's own batch with all threads (`value`), and beside it the same batch on one
+    thread and the reference's own batch of 32 sequences with all threads and with one."""
+    all_threads = torch.get_num_threads()
+    unit = "sequence-steps/s"
+    full_B = B
+    if T * B > 100000:
+        # a bounded sample of the workload: fewer sequences of the same length and shape
+        B = max(8, 16000 // T)
+    med, iters = _cpu_time_objective(T, B, net, burn_in, n, p, K, all_threads, budget_s, 30,
+                                     min_iters=3 if T <= 100 else 2)
+    out = {"value": T * B / med, "unit": unit, "cores": all_threads, "kind": "port",
+           "sample": f"{iters} fwd+bwd iterations of T={T} B={B}"
+                     + (f" (of the workload's {full_B} sequences)" if B != full_B else "")
+                     + f" (median {med*1e3:.1f} ms), "
+                     f"oracle/kalman_oracle.py with the {net} weight network, torch "
+                     f"{torch.__version__} CPU, {os.cpu_count()} logical CPUs visible",
+           "cpu_model": _cpu_model(), "also": []}
+    extra = [(B, 1, 6.0, 3)] if T * B <= 200000 else []
+    if B != 32 and T <= 50:
+        extra += [(32, all_threads, 3.0, 30), (32, 1, 3.0, 30)]
+    for b, threads, budget, cap in extra:
+        m, it = _cpu_time_objective(T, b, net, burn_in, n, p, K, threads, budget, cap)
+        out["also"].append({"batch": b, "cores": threads, "value": T * b / m, "unit": unit,
+                            "ms_per_iteration": m * 1e3, "iterations": it})
+    torch.set_num_threads(all_threads)
+    return out
 
+
+CONFIGS = {
+    # name: (T, B per GPU, p, n, K, steps, warmup)
+    "c1": dict(seq_len=20, batch=32, obs_dim=2, state_dim=4, bases=3),
+    "c2": dict(seq_len=20, batch=4096, obs_dim=2, state_dim=4, bases=3),
+    "c3": dict(seq_len=20, batch=1048576, obs_dim=2, state_dim=4, bases=3),
+    "c4": dict(seq_len=1000, batch=1024, obs_dim=16, state_dim=32, bases=8),
+    "c5": dict(seq_len=20, batch=128, obs_dim=2, state_dim=4, bases=3),
+}
+
+
+def _dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,8 +440,206 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return rank, world, dev, rehearsal
 
+
+def _fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(elapsed, world, dev, rehearsal):
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def _timed_steps(step, args, world, dev, rehearsal):
+    for _ in range(args.warmup):
+        step()
+    _fence(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _fence(world)
+    return _max_over_ranks(time.perf_counter() - t0, world, dev, rehearsal)
+
+
+def _base_result(args, world, units_per_step, elapsed, scaling, workload, extra_cfg):
+    return {
+        "metric": "filter+smoother sequence-steps/sec (fwd+bwd)", "value":
+        units_per_step * args.steps / elapsed, "unit": "sequence-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "config": dict({"workload": workload}, **extra_cfg)}
+
+
+# -- c3: masked imputation, forward only, the batch split over the ranks ----------------------
+def run_imputation(args, rank, world, dev, rehearsal):
+    from kalman_vae_amd import SampleControl
+    from kalman_vae_amd.parallel import shard_bounds
+    T, p, n, K = args.seq_len, args.obs_dim, args.state_dim, args.bases
+    total = args.batch
+    begin, end = shard_bounds(total, world, rank)
+    mine = end - begin
+    chunk = min(args.chunk, mine)
+    torch.manual_seed(0)
+    ssm = build_model(dev, torch.float32, args.net, n, p, K).eval()
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition="mean", observation="mean")
+    # one chunk of synthetic observations, reused for every chunk of the shard (the kernels'
+    # time does not depend on the values); resident in HBM before the timed region
+    a = bouncing_ball_observations(T, chunk, p, dev, seed=2000 + rank).to(torch.float32)
+    g = torch.Generator(device="cpu").manual_seed(3000 + rank)
+    mask = (torch.rand(T, chunk, generator=g) < 0.7).float()
+    mask[0] = 1.0
+    mask[-1] = 1.0
+    mask = mask.to(dev)
+    n_chunks = (mine + chunk - 1) // chunk
+
+    def step():
+        with torch.no_grad():
+            for _ in range(n_chunks):
+                out = ssm.kalman_filter(a, sc, observation_mask=mask)
+                ssm.kalman_smooth(a, *out[:6], sample_control=sc)
+
+    elapsed = _timed_steps(step, args, world, dev, rehearsal)
+    if rank != 0:
+        return None
+    units = T * n_chunks * chunk * world
+    res = _base_result(
+        args, world, units, elapsed, "strong",
+        f"masked imputation (filter + RTS smoother, forward only, keep probability 0.7, first "
+        f"and last step observed), T={T} a_dim={p} z_dim={n} K={K}, {total} sequences over "
+        f"{world} GPU(s) in chunks of {chunk}, {args.net} weight network",
+        {"seq_len": T, "total_sequences": total, "chunk": chunk, "parallelism": f"shard{world}",
+         "collectives": "none"})
+    res["metric"] = "filter+smoother sequence-steps/sec (masked imputation, forward)"
+    if not args.no_kernel_timing:
+        # the two stages of one chunk, HIP events around each
+        with torch.no_grad():
+            tf = _timed(lambda: ssm.kalman_filter(a, sc, observation_mask=mask), 5)
+            out = ssm.kalman_filter(a, sc, observation_mask=mask)
+            ts = _timed(lambda: ssm.kalman_smooth(a, *out[:6], sample_control=sc), 5)
+        el = 4
+        fb = el * ((p + 1) + (2 * n + 2 * n * n + n * n + p * n + p + K)) * T * chunk
+        sb = kernel_bytes(n, p, K, el)["smooth_forward"] * T * chunk
+        dom, sec, by = ("masked filter", tf, fb) if tf >= ts else ("smoother", ts, sb)
+        res["kernels"] = {"masked_filter": {"us": tf * 1e6, "GBps": fb / tf / 1e9},
+                          "smoother": {"us": ts * 1e6, "GBps": sb / ts / 1e9}}
+        res["roofline"] = {"kernel": dom + " stage of one chunk", "bound": "hbm",
+                           "achieved": by / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": by / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": by, "avg_launch_us": sec * 1e6}
+    return res
+
+
+# -- c5: the full model, conv encoder / decoder on 64x64 frames ----------------------------------
+def run_full_model(args, rank, world, dev, rehearsal):
+    from kalman_vae_amd import KalmanVariationalAutoencoder, SampleControl
+    from kalman_vae_amd.parallel import DataParallelStep
+    T, B, image = args.seq_len, args.batch, args.image
+    torch.manual_seed(1234)          # identical initial parameters on every rank
+    model = KalmanVariationalAutoencoder(
+        image_size=(image, image), image_channels=1, a_dim=args.obs_dim, z_dim=args.state_dim,
+        K=args.bases, init_transition_reg_weight=0.9, init_observation_reg_weight=0.9,
+        learn_noise_covariance=False, init_noise_scale=1.0,
+        dynamics_parameter_network=args.net, decoder_type="bernoulli").to(dev).train()
+    model.state_space_model.fused_loss = not args.separate_kernels
+    model.state_space_model.rng_parity = False
+    model.state_space_model.check_numerics = False
+    dp = DataParallelStep(model, torch.optim.Adam(model.parameters(), lr=1e-3))
+    torch.manual_seed(99 + rank)     # every rank its own synthetic frames
+    # binary discs of radius 4 px at the positions of a bouncing ball
+    pos = bouncing_ball_observations(T, B, 2, "cpu", seed=500 + rank)
+    yy, xx = torch.meshgrid(torch.arange(image), torch.arange(image), indexing="ij")
+    cx = ((pos[..., 0] + 1) * 0.5 * (image - 1)).view(T, B, 1, 1)
+    cy = ((pos[..., 1] + 1) * 0.5 * (image - 1)).view(T, B, 1, 1)
+    xs = (((xx - cx) ** 2 + (yy - cy) ** 2) <= 16.0).float().unsqueeze(2).to(dev)
+    sc = SampleControl()
+
+    def step():
+        dp(lambda: model.elbo(sc, xs=xs, burn_in=args.burn_in)[0])
+
+    elapsed = _timed_steps(step, args, world, dev, rehearsal)
+    if rank != 0:
+        return None
+    res = _base_result(
+        args, world, T * B * world, elapsed, "weak",
+        f"full Kalman-VAE training step (conv encoder/decoder, Kalman objective, backward, "
+        f"one flat gradient all-reduce, Adam), {image}x{image} frames, T={T}, {B} sequences per "
+        f"GPU, {args.net} weight network",
+        {"seq_len": T, "batch_per_gpu": B, "global_batch": B * world, "image": image,
+         "parallelism": f"dp{world}", "fused_objective": not args.separate_kernels})
+    res["metric"] = "full KVAE training step, sequence-steps/sec (= frames/sec)"
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="benchmark configuration (see the module docstring); sets the shape "
+                         "arguments below unless they are given")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (c3: in total)")
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--net", default=None, choices=["lstm", "mlp"])
+    ap.add_argument("--burn-in", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--state-dim", type=int, default=None)
+    ap.add_argument("--obs-dim", type=int, default=None)
+    ap.add_argument("--bases", type=int, default=None)
+    ap.add_argument("--chunk", type=int, default=65536, help="c3: sequences per call")
+    ap.add_argument("--image", type=int, default=64, help="c5: frame height and width")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="time only the six separate HIP kernels with synthetic mixing weights "
+                         "(softmax of N(0,1)); no PyTorch weight network, no autograd glue")
+    ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--separate-kernels", action="store_true",
+                    help="run filter, smoother and ELBO terms as six separate kernels with all "
+                         "their tensors materialised (the drop-in API's path) instead of the "
+                         "fused objective")
+    ap.add_argument("--no-hip-graph", action="store_true",
+                    help="run the step eagerly instead of replaying it as one HIP graph")
+    args = ap.parse_args()
+    for k, v in CONFIGS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.net is None:
+        # c3's default is the network the one-launch masked filter holds in LDS; every other
+        # configuration uses the reference's default network
+        args.net = "mlp" if args.config == "c3" else "lstm"
+    defaults = {"c1": (50, 10), "c2": (50, 10), "c3": (3, 1), "c4": (3, 1), "c5": (10, 3)}
+    if args.steps is None:
+        args.steps = defaults[args.config][0]
+    if args.warmup is None:
+        args.warmup = defaults[args.config][1]
+
+    rank, world, dev, rehearsal = _dist_setup(args)
+    result = None
+    if args.config == "c3":
+        result = run_imputation(args, rank, world, dev, rehearsal)
+    elif args.config == "c5":
+        result = run_full_model(args, rank, world, dev, rehearsal)
+    else:
+        result = run_training(args, rank, world, dev, rehearsal)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        result["config"]["name"] = args.config
+        print(json.dumps(result))
+
+
+def run_training(args, rank, world, dev, rehearsal):
     from kalman_vae_amd import SampleControl, kalman_elbo
+    from kalman_vae_amd import functions as F
     from kalman_vae_amd.parallel import FlatGradBucket
 
     T, B = args.seq_len, args.batch
@@ -341,22 +647,28 @@ def main():
     torch.manual_seed(0)   # same initial parameters on every rank
     n, p, K = args.state_dim, args.obs_dim, args.bases
     ssm = build_model(dev, dtype, args.net, n, p, K, fused=not args.separate_kernels)
+    fused = ssm.fused_loss and F.loss_supported(n, p, K, dtype)
     a = bouncing_ball_observations(T, B, p, dev, seed=1000 + rank).to(dtype).requires_grad_(True)
     bucket = FlatGradBucket(ssm.parameters()) if world > 1 else None
     sc = SampleControl()
+
+    def reduce_gradients():
+        # asynchronous on the collective's own stream: it overlaps the next replay, which
+        # reads no gradient; the next call waits for it before it refills the bucket
+        if bucket is not None:
+            bucket.all_reduce(average=True, async_op=not rehearsal)
 
     def eager_step():
         ssm.zero_grad(set_to_none=True)
         a.grad = None
         obj, _ = kalman_elbo(ssm, a, sc, burn_in=args.burn_in)
         (-obj).backward()
-        if bucket is not None:
-            bucket.all_reduce(average=True)
+        reduce_gradients()
 
-    # The whole step (weight network, filter, smoother, ELBO terms and their
-    # backward: ~90 launches) replayed as one HIP graph; same kernels, same work.
+    # The whole step (weight network, filter, smoother, ELBO terms and their backward)
+    # replayed as one HIP graph; same kernels, same work.
     graphed, graph_note = None, None
-    if not args.no_hip_graph and not args.kernels_only:
+    if not args.no_hip_graph and not args.kernels_only and T <= 100:
         from kalman_vae_amd.graphed import GraphedElboStep
         try:
             graphed = GraphedElboStep(ssm, a, sc, burn_in=args.burn_in)
@@ -366,108 +678,115 @@ def main():
 
     def graph_step():
         graphed(None)            # the synthetic batch already is the static input
-        if bucket is not None:
-            bucket.all_reduce(average=True)
+        reduce_gradients()
 
     step = graph_step if graphed is not None else eager_step
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     if args.kernels_only:
         kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters, synthetic_alpha=True)
         elapsed = sum(kt.values()) * args.steps
     else:
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    result = None
-    if rank == 0:
-        units = T * B
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * units * args.steps / elapsed
-        result = {
-            "metric": "filter+smoother sequence-steps/sec (fwd+bwd)",
-            "value": value, "unit": "sequence-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"bouncing-ball shapes T={T} a_dim={p} z_dim={n} K={K}, "
-                                   f"{B} sequences per GPU, "
-                                   + ("synthetic mixing weights, HIP kernels only, "
-                                      if args.kernels_only else f"{args.net} weight network, ")
-                                   + "filter+RTS smoother+ELBO terms fwd+bwd",
-                       "seq_len": T, "batch_per_gpu": B, "global_batch": B * world,
-                       "burn_in": args.burn_in,
-                       "parallelism": f"dp{world}" + (" (rehearsal: one GPU, gloo)" if rehearsal else ""),
-                       "hip_graph": graphed is not None},
-        }
-        if graph_note:
-            result["config"]["hip_graph_note"] = graph_note
-        if not args.no_kernel_timing:
+        elapsed = _timed_steps(step, args, world, dev, rehearsal)
+        if bucket is not None:
+            bucket.wait()
+    if rank != 0:
+        return None
+    units = T * B
+    result = _base_result(
+        args, world, world * units, elapsed, "weak",
+        f"bouncing-ball shapes T={T} a_dim={p} z_dim={n} K={K}, {B} sequences per GPU, "
+        + ("synthetic mixing weights, six separate HIP kernels only, " if args.kernels_only
+           else f"{args.net} weight network, ")
+        + "filter+RTS smoother+ELBO terms fwd+bwd"
+        + (" (fused objective: one launch per direction)" if fused and not args.kernels_only
+           else " (six separate kernels)"),
+        {"seq_len": T, "batch_per_gpu": B, "global_batch": B * world, "burn_in": args.burn_in,
+         "parallelism": f"dp{world}" + (" (rehearsal: one GPU, gloo)" if rehearsal else ""),
+         "hip_graph": graphed is not None, "fused_objective": bool(fused)})
+    if graph_note:
+        result["config"]["hip_graph_note"] = graph_note
+    step_s = elapsed / args.steps
+    fl = flops_forward(n, p, K)
+    step_flops = 3 * sum(fl.values()) * units
+    # the whole timed step against the algorithmic work of the Kalman path alone
+    result["valu_frac_step"] = step_flops / step_s / 1e12 / VALU_FP32_PEAK_TF
+    if not args.no_kernel_timing:
+        kernels = {}
+        kal = None      # (name, seconds, flops, bytes) of the Kalman path's longest kernel
+        if fused and not args.kernels_only:
+            ft = time_fused_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
+            fb = fused_bytes(n, p, K, 4)
+            ffl = {"loss_forward": sum(fl.values()), "loss_backward": 2 * sum(fl.values())}
+            for name, sec in ft.items():
+                kernels[name] = {"us": sec * 1e6, "GBps": fb[name] * units / sec / 1e9,
+                                 "TFLOPs": ffl[name] * units / sec / 1e12}
+            dom = max(ft, key=ft.get)
+            kal = (dom, ft[dom], ffl[dom] * units, fb[dom] * units)
+            total_k = sum(ft.values())
+            note = ("the fused objective's two launches (plus their row sums) with the weight "
+                    "network's mixing weights; excludes the weight network and the noise draw")
+        else:
             if not args.kernels_only:
                 kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
-            fl = flops_forward(n, p, K)
             kb = kernel_bytes(n, p, K, 4)
             kflops = {"filter_forward": fl["filter"], "filter_backward": 2 * fl["filter"],
                       "smooth_forward": fl["smooth"], "smooth_backward": 2 * fl["smooth"],
                       "elbo_forward": fl["elbo"], "elbo_backward": 2 * fl["elbo"]}
-            kernels = {}
             for name, sec in kt.items():
                 kernels[name] = {"us": sec * 1e6, "GBps": kb[name] * units / sec / 1e9,
                                  "TFLOPs": kflops[name] * units / sec / 1e12}
             dom = max(kt, key=kt.get)
-            achieved = kb[dom] * units / kt[dom] / 1e9
-            # HBM bytes per launch counted by the PMC passes committed under profiles/
-            # (rocprofv3 cannot run inside this process); null for shapes not profiled
-            traffic = None
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                       "pmc_hbm_traffic.json")) as fh:
-                    traffic = json.load(fh).get(f"T{T}_B{B}_n{n}_p{p}_K{K}", {}).get(dom)
-            except OSError:
-                pass
-            result["roofline"] = {
-                "kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": kb[dom] * units,
-                "avg_launch_us": kt[dom] * 1e6,
-                "valu_frac": kflops[dom] * units / kt[dom] / 1e12 / VALU_FP32_PEAK_TF,
-            }
+            kal = (dom, kt[dom], kflops[dom] * units, kb[dom] * units)
             total_k = sum(kt.values())
-            if not args.kernels_only:
-                # the weight network's recurrence: the longest kernels of the whole step,
-                # bound by the fp32 matrix core rather than by HBM
-                lk = time_lstm_kernels(ssm, a)
-                if lk is not None:
-                    result["weight_network_kernels"] = lk
-            result["kernels"] = kernels
-            result["kernel_only"] = {
-                "us_per_step": total_k * 1e6,
-                "sequence_steps_per_s": units / total_k,
-                "valu_frac": 3 * sum(fl.values()) * units / total_k / 1e12 / VALU_FP32_PEAK_TF,
-                "note": "sum of the six HIP kernels with precomputed mixing weights; excludes "
-                        "the PyTorch weight network, noise draws and autograd glue",
-            }
-        if world == 1 and not args.no_cpu_baseline and not args.kernels_only:
-            result["cpu_baseline"] = cpu_baseline(T, B, args.net, args.burn_in, n, p, K)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+            note = ("sum of the six HIP kernels with precomputed mixing weights; excludes the "
+                    "weight network, noise draws and autograd glue")
+        # HBM bytes per launch counted by the PMC passes committed under profiles/
+        # (rocprofv3 cannot run inside this process); null for shapes not profiled
+        traffic_table = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as fh:
+                traffic_table = json.load(fh).get(f"T{T}_B{B}_n{n}_p{p}_K{K}", {})
+        except OSError:
+            pass
+        name, sec, flops, by = kal
+        # which roof bounds the Kalman kernel: arithmetic intensity against the ridge
+        # (157.3 TFLOP/s / 8 TB/s = 19.7 flop/B)
+        valu_bound = flops / by > VALU_FP32_PEAK_TF * 1e3 / HBM_PEAK_GBS
+        kal_roof = {
+            "kernel": name, "bound": "valu" if valu_bound else "hbm",
+            "achieved": flops / sec / 1e12 if valu_bound else by / sec / 1e9,
+            "peak": VALU_FP32_PEAK_TF if valu_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if valu_bound else "GB/s",
+            "traffic": traffic_table.get(name), "algorithmic_bytes_per_launch": by,
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6,
+            "valu_frac": flops / sec / 1e12 / VALU_FP32_PEAK_TF,
+            "hbm_frac": by / sec / 1e9 / HBM_PEAK_GBS}
+        kal_roof["frac"] = kal_roof["achieved"] / kal_roof["peak"]
+        result["kalman_roofline"] = kal_roof
+        result["roofline"] = dict(kal_roof)
+        if not args.kernels_only:
+            # the weight network's recurrence: the longest kernels of the whole step, bound
+            # by the fp32 matrix core
+            lk = time_lstm_kernels(ssm, a)
+            if lk is not None:
+                result["weight_network_kernels"] = lk
+                top = max(lk, key=lambda k_: lk[k_]["us"])
+                if lk[top]["us"] * 1e-6 > sec:
+                    r = lk[top]
+                    result["roofline"] = {
+                        "kernel": r["kernel"], "bound": "mfma", "achieved": r["achieved"],
+                        "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                        "traffic": traffic_table.get(top), "avg_launch_us": r["us"],
+                        "algorithmic_flops_per_launch": r["flops_per_launch"],
+                        "algorithmic_bytes_per_launch": r["hbm_bytes_per_launch"],
+                        "share_of_step": r["us"] * 1e-6 / step_s}
+        result["kernels"] = kernels
+        result["kernel_only"] = {
+            "us_per_step": total_k * 1e6, "sequence_steps_per_s": units / total_k,
+            "valu_frac": step_flops / total_k / 1e12 / VALU_FP32_PEAK_TF, "note": note}
+    if world == 1 and not args.no_cpu_baseline and not args.kernels_only:
+        result["cpu_baseline"] = cpu_baseline(T, B, args.net, args.burn_in, n, p, K)
+    return result
 
 
 if __name__ == "__main__":

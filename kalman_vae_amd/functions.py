@@ -216,7 +216,11 @@ class KalmanFilterFunction(torch.autograd.Function):
                        status=status_word(a.device))
         capi.check(capi.load().kvae_filter_forward(C.byref(dims), C.byref(io),
                                                    capi.current_stream_ptr()))
-        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn)
+        # the mixed per-step matrices are outputs of the forward call; the large-state
+        # register-tile backward kernel reads them back instead of re-mixing (null makes
+        # the library fall back to its LDS kernel)
+        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn,
+                              *((As, Cs) if want_mats else ()))
         ctx.dims = dims
         ctx.set_materialize_grads(False)
         if not want_mats:
@@ -226,7 +230,8 @@ class KalmanFilterFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_m, g_P, g_mn, g_Pn, g_As, g_Cs):
-        a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn = ctx.saved_tensors
+        a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn = ctx.saved_tensors[:13]
+        As, Cs = ctx.saved_tensors[13:] if len(ctx.saved_tensors) > 13 else (None, None)
         # contiguous copies must outlive the launch: keep them in locals
         g_m, g_P, g_mn, g_Pn, g_As, g_Cs = map(_c, (g_m, g_P, g_mn, g_Pn, g_As, g_Cs))
         dims = ctx.dims
@@ -238,7 +243,7 @@ class KalmanFilterFunction(torch.autograd.Function):
         io = capi.FilterBwd()
         capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m_in=m_in,
                   P_in=P_in, carry_per_sequence=int(m_in.dim() == 2), mean_filt=m, cov_filt=P,
-                  mean_pred=mn, cov_pred=Pn)
+                  mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs)
         capi.fill(io, g_mean_filt=g_m, g_cov_filt=g_P, g_mean_pred=g_mn,
                   g_cov_pred=g_Pn, g_mat_As=g_As, g_mat_Cs=g_Cs, d_a=d_a,
                   d_alpha=d_alpha, d_m_in=d_m_in, d_P_in=d_P_in, d_A_K=d_A_K, d_C_K=d_C_K,

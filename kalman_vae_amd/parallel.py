@@ -26,10 +26,18 @@ def shard_batch(tensor, world_size, rank, dim=1):
 class FlatGradBucket:
     """All gradients of `params` in ONE flat buffer and one all-reduce.
 
-    The Kalman model has ~0.2-0.25 M parameters (< 1 MB in fp32): at that size
-    a collective is latency-bound, so a single bucket (one launch, one ring or
-    tree pass) beats per-tensor or multi-bucket reduction.  Gradients are
-    copied in with one fused multi-tensor copy and copied back the same way.
+    The Kalman model has ~0.2-0.25 M parameters (< 1 MB in fp32): at that size a
+    collective is latency-bound, so a single bucket (one launch, one ring or tree pass)
+    beats per-tensor or multi-bucket reduction.
+
+    Per step: ONE fused multi-tensor copy gathers the gradients autograd produced into
+    the flat buffer, the all-reduce averages it in place (``ReduceOp.AVG`` where the
+    backend has it: no separate division), and every parameter's ``.grad`` is re-pointed
+    at its slice of the buffer -- no copy back.  Parameters that received no gradient keep
+    ``grad = None`` (the optimizer skips them, as on a single device) and their slices
+    stay zero.  ``async_op=True`` returns the collective's work handle: the reduction runs
+    on the backend's own stream, and the caller waits on the handle before reading the
+    gradients (or before the next ``all_reduce``).
     """
 
     def __init__(self, params):
@@ -43,36 +51,57 @@ class FlatGradBucket:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._pending = None
+
+    def wait(self):
+        """Block the current stream until the last asynchronous all-reduce is done."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
 
     def pack(self):
-        self.flat.zero_()
-        src = [p.grad for p in self.params if p.grad is not None]
-        dst = [v for p, v in zip(self.params, self.views) if p.grad is not None]
+        """Gather the gradients that do not already live in the buffer (one launch)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
 
-    def unpack(self):
+    def bind(self):
+        """Point the gradient of every parameter that has one at its slice of the buffer."""
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            if p.grad is not None:
+                p.grad = v
 
-    def all_reduce(self, average=True, group=None):
-        """Sum (or average) the gradients over all ranks, in place."""
+    def all_reduce(self, average=True, group=None, async_op=False):
+        """Sum (or average) the gradients over all ranks, in place in the flat buffer."""
+        self.wait()
         self.pack()
+        work = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+            backend = dist.get_backend(group)
+            if self.flat.is_cuda and backend == "gloo":
                 # gloo reduces host memory (its device path hangs on this ROCm build);
                 # only rehearsals and tests pair gloo with GPU tensors
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                if average:
+                    host /= dist.get_world_size(group)
                 self.flat.copy_(host)
+            elif backend == "nccl":
+                op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM
+                work = dist.all_reduce(self.flat, op=op, group=group, async_op=async_op)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                self.flat.div_(dist.get_world_size(group))
-        self.unpack()
+                if average:
+                    self.flat.div_(dist.get_world_size(group))
+        self.bind()
+        if async_op and work is not None:
+            self._pending = work
+            return work
         return self.flat
 
 

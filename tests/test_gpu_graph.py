@@ -323,3 +323,44 @@ def test_masked_inference_path_equals_autograd_path(net, dtype, tol, in_kernel, 
     for x, y in zip(fast, slow):
         assert x.shape == y.shape
         assert rel_err(x, y.detach()) < tol
+
+
+def test_module_large_state_backward_runs_the_register_tile_kernel():
+    """The module's training path at a large state dimension (fp32, z_dim=32): the filter
+    backward must run the register-tile kernel (it needs the mixed per-step matrices the
+    forward call wrote, which the autograd node therefore keeps), and its gradients must
+    agree with the LDS kernel family's."""
+    import os
+    from torch.profiler import ProfilerActivity, profile
+    from kalman_vae_amd import SampleControl, StateSpaceModel, kalman_elbo
+    dev = torch.device("cuda:0")
+
+    def run(family, trace):
+        os.environ["KVAE_LARGE_STATE"] = family
+        try:
+            torch.manual_seed(11)
+            ssm = StateSpaceModel(a_dim=16, z_dim=32, K=8, dynamics_parameter_network="mlp",
+                                  hidden_dim=16).to(dev).train()
+            ssm.rng_parity = False
+            a = (0.5 * torch.randn(6, 5, 16, device=dev)).requires_grad_(True)
+            torch.manual_seed(12)
+
+            def step():
+                obj, _ = kalman_elbo(ssm, a, SampleControl(), burn_in=1)
+                return torch.autograd.grad(obj, [a, ssm._mat_A_K, ssm._mat_C_K])
+            if not trace:
+                return step(), []
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                g = step()
+                torch.cuda.synchronize()
+            return g, [e.name for e in prof.events()]
+        finally:
+            os.environ.pop("KVAE_LARGE_STATE", None)
+
+    g_tile, names = run("tile", True)
+    g_lds, _ = run("lds", False)
+    for x, y in zip(g_tile, g_lds):
+        assert float((x - y).abs().max()) < 2e-4 * float(y.abs().max())
+    kernels = [n for n in names if "kvae" in n]
+    if kernels:      # the profiler saw device kernels
+        assert any("tile_filter_backward" in n for n in kernels), sorted(set(kernels))

@@ -72,6 +72,42 @@ def test_flat_bucket_allreduce_matches_full_batch(tmp_path):
     assert float((got - want).abs().max()) < 1e-10 * max(1.0, float(want.abs().max()))
 
 
+def test_bucket_gathers_with_one_launch_and_copies_nothing_back(monkeypatch):
+    """One fused multi-tensor copy per step, gradients re-pointed at the flat buffer (no
+    copy back), parameters without a gradient left at grad = None."""
+    model, a, eps = _make()
+    _objective(model, a, eps).backward()
+    had = {n for n, p in model.named_parameters() if p.grad is not None}
+    assert "a_0" not in had and "_mat_Q_L" not in had      # no gradient on a single device
+    want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    bucket = FlatGradBucket(model.parameters())
+    calls = {"foreach": 0, "copy": 0}
+    real_foreach, real_copy = torch._foreach_copy_, torch.Tensor.copy_
+
+    def count_foreach(dst, src, *a_, **k_):
+        calls["foreach"] += 1
+        return real_foreach(dst, src, *a_, **k_)
+
+    def count_copy(self, *a_, **k_):
+        calls["copy"] += 1
+        return real_copy(self, *a_, **k_)
+
+    monkeypatch.setattr(torch, "_foreach_copy_", count_foreach)
+    monkeypatch.setattr(torch.Tensor, "copy_", count_copy)
+    bucket.all_reduce(average=True)
+    assert calls == {"foreach": 1, "copy": 0}
+    by_name = dict(model.named_parameters())
+    for (n, p), v in zip(((n, by_name[n]) for n in by_name if by_name[n].requires_grad),
+                         bucket.views):
+        if n in had:
+            assert p.grad.data_ptr() == v.data_ptr()          # a view of the bucket
+            assert torch.equal(p.grad, want[n])
+        else:
+            assert p.grad is None and float(v.abs().max()) == 0.0
+    bucket.all_reduce(average=True)                            # gradients already in place
+    assert calls == {"foreach": 1, "copy": 0}
+
+
 # -- DataParallelStep over the full model's parameters ------------------------------
 def _full_model(seed=3):
     from kalman_vae_amd import KalmanVariationalAutoencoder
