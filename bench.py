@@ -333,6 +333,11 @@ def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
     return out
 
 
+def _progress(msg):
+    """A line on stderr (long configurations must not look hung)."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -386,23 +391,29 @@ def cpu_baseline(T, B, net, burn_in, n=4, p=2, K=3, budget_s=12.0):
     thread and the reference's own batch of 32 sequences with all threads and with one."""
     all_threads = torch.get_num_threads()
     unit = "sequence-steps/s"
-    full_B = B
+    full_B, full_T = B, T
     if T * B > 100000:
-        # a bounded sample of the workload: fewer sequences of the same length and shape
-        B = max(8, 16000 // T)
+        # a bounded sample of the workload: fewer and shorter sequences of the same shape
+        # (the oracle's cost per sequence-step is what is measured; 1000 steps of 16
+        # sequences at z_dim=32 take over a minute per iteration)
+        T = min(T, 100)
+        B = max(8, 1600 // T)
+    _progress(f"cpu baseline: oracle at T={T} B={B}, {all_threads} threads")
     med, iters = _cpu_time_objective(T, B, net, burn_in, n, p, K, all_threads, budget_s, 30,
-                                     min_iters=3 if T <= 100 else 2)
+                                     min_iters=3 if full_T <= 100 else 2)
     out = {"value": T * B / med, "unit": unit, "cores": all_threads, "kind": "port",
            "sample": f"{iters} fwd+bwd iterations of T={T} B={B}"
-                     + (f" (of the workload's {full_B} sequences)" if B != full_B else "")
+                     + (f" (a sample of the workload's T={full_T} B={full_B})"
+                        if (B, T) != (full_B, full_T) else "")
                      + f" (median {med*1e3:.1f} ms), "
                      f"oracle/kalman_oracle.py with the {net} weight network, torch "
                      f"{torch.__version__} CPU, {os.cpu_count()} logical CPUs visible",
            "cpu_model": _cpu_model(), "also": []}
-    extra = [(B, 1, 6.0, 3)] if T * B <= 200000 else []
-    if B != 32 and T <= 50:
+    extra = [(B, 1, 6.0, 3)] if full_T * full_B <= 200000 else []
+    if B != 32 and full_T <= 50:
         extra += [(32, all_threads, 3.0, 30), (32, 1, 3.0, 30)]
     for b, threads, budget, cap in extra:
+        _progress(f"cpu baseline: oracle at T={T} B={b}, {threads} thread(s)")
         m, it = _cpu_time_objective(T, b, net, burn_in, n, p, K, threads, budget, cap)
         out["also"].append({"batch": b, "cores": threads, "value": T * b / m, "unit": unit,
                             "ms_per_iteration": m * 1e3, "iterations": it})
@@ -462,6 +473,7 @@ def _timed_steps(step, args, world, dev, rehearsal):
     for _ in range(args.warmup):
         step()
     _fence(world)
+    _progress(f"{args.warmup} warm-up steps done, timing {args.steps} steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -711,6 +723,7 @@ def run_training(args, rank, world, dev, rehearsal):
     # the whole timed step against the algorithmic work of the Kalman path alone
     result["valu_frac_step"] = step_flops / step_s / 1e12 / VALU_FP32_PEAK_TF
     if not args.no_kernel_timing:
+        _progress("timing individual kernels")
         kernels = {}
         kal = None      # (name, seconds, flops, bytes) of the Kalman path's longest kernel
         if fused and not args.kernels_only:

@@ -243,9 +243,16 @@ class ResidentLSTM2Function(torch.autograd.Function):
                                                       b_hh1)
         wih0 = w_ih0.contiguous()
         stream = capi.current_stream_ptr()
-        capi.check(lib.kvae_lstm128_forward(
-            T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
-            gates0.data_ptr(), h0.data_ptr(), c0.data_ptr(), None, None, 1, stream))
+        if P <= 4:
+            capi.check(lib.kvae_lstm128_forward(
+                T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
+                gates0.data_ptr(), h0.data_ptr(), c0.data_ptr(), None, None, 1, stream))
+        else:
+            # a wide input: its projection of all steps is one library GEMM, like layer 1's
+            torch.addmm(b0, x.view(T * B, P), wih0.t(), out=gates0.view(T * B, 4 * H))
+            capi.check(lib.kvae_lstm128_forward(
+                T, B, 0, None, None, None, whh0t.data_ptr(), gates0.data_ptr(), h0.data_ptr(),
+                c0.data_ptr(), None, None, 1, stream))
         # layer 1's input projection of all steps: (T*B,128) x (128,512) + bias
         torch.addmm(b1, h0.view(T * B, H), wih1t, out=gates1.view(T * B, 4 * H))
         capi.check(lib.kvae_lstm128_forward(
@@ -267,7 +274,8 @@ class ResidentLSTM2Function(torch.autograd.Function):
         dx = torch.empty_like(x)
         blocks = lib.kvae_lstm128_blocks(B)
         part1 = torch.empty(blocks, 4 * H * 2, dtype=x.dtype, device=x.device)
-        part0 = torch.empty(blocks, 4 * H * (2 + P), dtype=x.dtype, device=x.device)
+        Pk = P if P <= 4 else 0          # input dimension the layer-0 kernel handles itself
+        part0 = torch.empty(blocks, 4 * H * (2 + Pk), dtype=x.dtype, device=x.device)
         wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
         stream = capi.current_stream_ptr()
         capi.check(lib.kvae_lstm128_backward(
@@ -276,14 +284,23 @@ class ResidentLSTM2Function(torch.autograd.Function):
         d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
         # gradient w.r.t. layer 0's h through layer 1's input product
         g_h0 = torch.mm(d1, wih1).view(T, B, H)
-        capi.check(lib.kvae_lstm128_backward(
-            T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
-            g_h0.data_ptr(), whh0.data_ptr(), dG0.data_ptr(), dx.data_ptr(), part0.data_ptr(),
-            stream))
+        if Pk:
+            capi.check(lib.kvae_lstm128_backward(
+                T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
+                g_h0.data_ptr(), whh0.data_ptr(), dG0.data_ptr(), dx.data_ptr(),
+                part0.data_ptr(), stream))
+        else:
+            capi.check(lib.kvae_lstm128_backward(
+                T, B, 0, None, None, gates0.data_ptr(), c0.data_ptr(), None, g_h0.data_ptr(),
+                whh0.data_ptr(), dG0.data_ptr(), None, part0.data_ptr(), stream))
         s1, s0 = capi.column_sum(part1), capi.column_sum(part0)
         db1, db1b = s1[:4 * H], s1[4 * H:]
         db0, db0b = s0[:4 * H], s0[4 * H:8 * H]
-        dw_ih0 = s0[8 * H:].view(4 * H, P)
+        if Pk:
+            dw_ih0 = s0[8 * H:].view(4 * H, P)
+        else:
+            torch.mm(d0, wih0, out=dx.view(T * B, P))
+            dw_ih0 = _splitk_tn(d0, x.view(T * B, P))
         zero = lambda w: torch.zeros_like(w)
         if T > 1:
             dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
@@ -440,7 +457,8 @@ def fused_lstm(x, lstm):
     for l in range(lstm.num_layers):
         params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
                    getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
-    if lstm.num_layers == 2 and lstm.hidden_size == 128 and x.shape[2] <= 4 and PERSISTENT:
+    two_layer_128 = lstm.num_layers == 2 and lstm.hidden_size == 128 and PERSISTENT
+    if two_layer_128 and (x.shape[2] <= 4 or RESIDENT):
         fn = ResidentLSTM2Function if RESIDENT else FusedLSTM2Function
         out, h0, c0, c1 = fn.apply(x, *params)
         return out, LastState((h0[-1], out.detach()[-1]), (c0[-1], c1[-1]))
