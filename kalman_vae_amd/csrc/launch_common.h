@@ -18,6 +18,7 @@ constexpr int WAVE = 64;
     X(4, 2, 3)           \
     X(2, 1, 2)           \
     X(3, 2, 2)           \
+    X(4, 2, 8)           \
     X(8, 4, 4)
 
 // Lane exchange inside a row of 16 lanes by a DPP control word (no LDS crossbar).

@@ -49,8 +49,8 @@ def _dims(T, B, n, p, K, dtype, symmetrize, burn_in):
     code = capi.dtype_code(dtype)
     if not lib.kvae_supported(n, p, K, code):
         raise NotImplementedError(
-            f"no HIP kernel compiled for z_dim={n}, a_dim={p}, K={K}; add the "
-            "combination to KVAE_DIM_LIST in kalman_vae_amd/csrc/kernels.hip")
+            f"no HIP kernel compiled for z_dim={n}, a_dim={p}, K={K}; the public "
+            "kalman_* functions of this module embed such a problem into a compiled one")
     return capi.Dims(T, B, n, p, K, code, int(bool(symmetrize)), int(max(0, burn_in)))
 
 
@@ -59,13 +59,120 @@ def _workspace(dims, op, device):
     return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device), int(nbytes)
 
 
-def _any_K(n, p):
+# ---------------------------------------------------------------------------
+# Dimension embedding.  Kernels exist for a fixed list of (z_dim, a_dim, K).  Any
+# other combination that fits inside a compiled one is solved EXACTLY as a block of
+# the larger problem: with
+#   A' = diag(A, 0), C' = [[C, 0], [0, 0]], Q' = diag(Q, I), R' = diag(R, I),
+#   m0' = (m0, 0), P0' = diag(P0, I), a' = (a, 0), alpha' = (alpha, 0), eps' = (eps, 0)
+# the extra state stays N(0, I), independent of the real block (every cross term is an
+# exact zero), the filter / smoother outputs of the real block are unchanged, and each
+# extra dimension adds the constant -log(2 pi)/2 to a Gaussian log-density term.  The
+# padding and the slicing are differentiable torch ops, so gradients flow through.
+# ---------------------------------------------------------------------------
+LOG_2PI = 1.8378770664093453
+MAX_Z_DIM, MAX_A_DIM, MAX_K = 32, 16, 8
+_compiled = {}
+
+
+def compiled_shapes(dtype, fused=False):
+    """Every (z_dim, a_dim, K) the library has kernels for (``fused``: the one-launch
+    objective), probed once."""
+    code = capi.dtype_code(dtype)
+    key = (code, bool(fused))
+    if key not in _compiled:
+        lib = capi.load()
+        probe = lib.kvae_loss_supported if fused else lib.kvae_supported
+        _compiled[key] = [(n, p, K) for n in range(1, MAX_Z_DIM + 1)
+                          for p in range(1, MAX_A_DIM + 1) for K in range(1, MAX_K + 1)
+                          if probe(n, p, K, code)]
+    return _compiled[key]
+
+
+def embedding_dims(n, p, K, dtype, fused=False):
+    """The cheapest compiled (n2, p2, K2) with n2 >= n, p2 >= p, K2 >= K (K None: the
+    op does not depend on K), or None."""
+    fits = [s for s in compiled_shapes(dtype, fused)
+            if s[0] >= n and s[1] >= p and (K is None or s[2] >= K)]
+    return min(fits) if fits else None
+
+
+def _require_embedding(n, p, K, dtype):
+    dims = embedding_dims(n, p, K, dtype)
+    if dims is None:
+        raise NotImplementedError(
+            f"no HIP kernel covers z_dim={n}, a_dim={p}, K={K} (limits: z_dim <= "
+            f"{MAX_Z_DIM}, a_dim <= {MAX_A_DIM}, K <= {MAX_K}); add the combination to "
+            "KVAE_DIM_LIST in kalman_vae_amd/csrc/launch_common.h")
+    return dims
+
+
+class _Embedding:
+    """Pads operands of an (n, p, K) problem to (n2, p2, K2) and cuts results back."""
+
+    def __init__(self, n, p, K, n2, p2, K2):
+        self.n, self.p, self.K, self.n2, self.p2, self.K2 = n, p, K, n2, p2, K2
+        self.dn, self.dp, self.dK = n2 - n, p2 - p, (K2 - K) if K is not None else 0
+        self.identity = (self.dn, self.dp, self.dK) == (0, 0, 0)
+        # what one (t, b) pair of each padded log-density term lacks
+        self.c_obs, self.c_lat = 0.5 * self.dp * LOG_2PI, 0.5 * self.dn * LOG_2PI
+
+    @staticmethod
+    def _pad(t, *widths):
+        if t is None or not any(widths):
+            return t
+        spec = []
+        for w in widths:            # last dimension first
+            spec += [0, w]
+        return torch.nn.functional.pad(t, spec)
+
+    @staticmethod
+    def _tail(k, k2, like):
+        key = ("tail", k, k2, like.dtype, like.device.type, like.device.index)
+        if key not in _constant_vectors:
+            d = torch.zeros(k2, dtype=like.dtype, device=like.device)
+            d[k:] = 1
+            _constant_vectors[key] = torch.diag(d)
+        return _constant_vectors[key]
+
+    def vec_n(self, t): return self._pad(t, self.dn)
+    def vec_p(self, t): return self._pad(t, self.dp)
+    def weights(self, t): return self._pad(t, self.dK)
+    def mat_nn(self, t): return self._pad(t, self.dn, self.dn)
+    def mat_pn(self, t): return self._pad(t, self.dn, self.dp)
+    def bases_A(self, t): return self._pad(t, self.dn, self.dn, self.dK)
+    def bases_C(self, t): return self._pad(t, self.dn, self.dp, self.dK)
+
+    def cov_n(self, t):
+        if t is None or not self.dn:
+            return t
+        return self._pad(t, self.dn, self.dn) + self._tail(self.n, self.n2, t)
+
+    def cov_p(self, t):
+        if t is None or not self.dp:
+            return t
+        return self._pad(t, self.dp, self.dp) + self._tail(self.p, self.p2, t)
+
+    def cut_n(self, t): return t[..., :self.n].contiguous() if self.dn else t
+    def cut_p(self, t): return t[..., :self.p].contiguous() if self.dp else t
+    def cut_K(self, t): return t[..., :self.K].contiguous() if self.dK else t
+    def cut_nn(self, t): return t[..., :self.n, :self.n].contiguous() if self.dn else t
+
+    def cut_pn(self, t):
+        return t[..., :self.p, :self.n].contiguous() if (self.dn or self.dp) else t
+
+
+def _embedding(n, p, K, dtype, fused=False):
+    dims = embedding_dims(n, p, K, dtype, fused) if fused else _require_embedding(n, p, K, dtype)
+    return None if dims is None else _Embedding(n, p, K, *dims)
+
+
+def _any_K(n, p, dtype=torch.float32):
     """The smoother and ELBO kernels do not depend on K, but kernels are keyed on
     (n, p, K): use any K compiled for this (n, p)."""
-    lib = capi.load()
-    for K in range(1, 33):
-        if lib.kvae_supported(n, p, K, capi.KVAE_F32):
-            return K
+    for s in compiled_shapes(dtype):
+        if s[0] == n and s[1] == p:
+            return s[2]
     raise NotImplementedError(f"no HIP kernel compiled for z_dim={n}, a_dim={p}")
 
 
@@ -268,7 +375,7 @@ class KalmanSmoothFunction(torch.autograd.Function):
             _c, (m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs))
         T, B, n = m.shape
         p = Cs.shape[2]
-        dims = _dims(T, B, n, p, _any_K(n, p), m.dtype, symmetrize, burn_in)
+        dims = _dims(T, B, n, p, _any_K(n, p, m.dtype), m.dtype, symmetrize, burn_in)
         new = lambda *s: torch.empty(s, dtype=m.dtype, device=m.device)
         ms, Ps, zs, ares = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, p)
         io = capi.fill(capi.SmoothFwd(), mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn,
@@ -316,7 +423,7 @@ class KalmanElboFunction(torch.autograd.Function):
         a, ms, Ps, As, Cs, Q, R, m0, P0, eps = map(_c, (a, ms, Ps, As, Cs, Q, R, m0, P0, eps))
         T, B, n = ms.shape
         p = a.shape[2]
-        dims = _dims(T, B, n, p, _any_K(n, p), a.dtype, True, 0)
+        dims = _dims(T, B, n, p, _any_K(n, p, a.dtype), a.dtype, True, 0)
         new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
         # the three terms live in one (3,T,B) buffer so that they can be totalled by
         # one launch (term_totals)
@@ -371,7 +478,7 @@ class KalmanElboObjectiveFunction(torch.autograd.Function):
         lib = capi.load()
         T, B, n = ms.shape
         p = a.shape[2]
-        dims = _dims(T, B, n, p, _any_K(n, p), a.dtype, True, 0)
+        dims = _dims(T, B, n, p, _any_K(n, p, a.dtype), a.dtype, True, 0)
         new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
         terms, z, out = new(3, T, B), new(T, B, n), new(4)
         io = capi.fill(capi.ElboFwd(), a=a, mean_smooth=ms, cov_smooth=Ps, mat_As=As, mat_Cs=Cs,
@@ -494,17 +601,42 @@ class KalmanLossFunction(torch.autograd.Function):
                 None, None, None)
 
 
+def _shift_totals(objective, weighted, terms, count, shifts, like):
+    """Add per-(t, b) constants ``shifts`` (already multiplied by the term weights for the
+    totals) to the outputs of an objective call."""
+    (c_obs, c_trans, c_post), (w_obs, w_trans, w_post) = shifts
+    add = (w_obs * c_obs * count, w_trans * c_trans * count, w_post * c_post * count)
+    weighted = weighted + constant_vector(add, like)
+    objective = objective + sum(add)
+    if terms is not None and terms.numel():
+        terms = terms + constant_vector((c_obs, c_trans, c_post), like).view(3, 1, 1)
+    return objective, weighted, terms
+
+
 def kalman_loss(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, w_obs, w_trans, w_post,
                 symmetrize=True, burn_in=0, want_terms=False):
     """(objective, weighted totals (3,), terms (3,T,B) or empty): see KalmanLossFunction."""
-    return KalmanLossFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, float(w_obs),
-                                    float(w_trans), float(w_post), bool(symmetrize), int(burn_in),
-                                    bool(want_terms))
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    e = _embedding(n, p, K, a.dtype, fused=True)
+    if e is None:
+        raise NotImplementedError(
+            f"no fused-objective kernel covers z_dim={n}, a_dim={p}, K={K}")
+    w = (float(w_obs), float(w_trans), float(w_post))
+    if e.identity:
+        return KalmanLossFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, *w,
+                                        bool(symmetrize), int(burn_in), bool(want_terms))
+    objective, weighted, terms = KalmanLossFunction.apply(
+        e.vec_p(a), e.weights(alpha), mask, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q),
+        e.cov_p(R), e.vec_n(m0), e.cov_n(P0), e.vec_n(eps), *w, bool(symmetrize), int(burn_in),
+        bool(want_terms))
+    return _shift_totals(objective, weighted, terms, T * B, ((e.c_obs, e.c_lat, e.c_lat), w), a)
 
 
 def loss_supported(n, p, K, dtype):
-    """Whether the fused objective has a kernel for these dimensions."""
-    return bool(capi.load().kvae_loss_supported(n, p, K, capi.dtype_code(dtype)))
+    """Whether the fused objective has a kernel for these dimensions (directly or as a
+    block of a larger compiled problem)."""
+    return embedding_dims(n, p, K, dtype, fused=True) is not None
 
 
 @torch.no_grad()
@@ -518,6 +650,13 @@ def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a
     B, K = w.shape
     n, p = m_pred.shape[1], a.shape[1]
     code = capi.dtype_code(a.dtype)
+    dims2 = embedding_dims(n, p, K, a.dtype)
+    if dims2 is not None and dims2 != (n, p, K):
+        e = _Embedding(n, p, K, *dims2)
+        a_w = impute_observation(e.weights(w), e.bases_A(A_K), e.bases_C(C_K), e.vec_n(m_pred),
+                                 e.vec_p(a), mask, e.vec_n(eps_z), e.cov_n(L_Q), e.vec_p(eps_a),
+                                 e.cov_p(L_R))
+        return None if a_w is None else e.cut_p(a_w)
     dims = capi.Dims(1, B, n, p, K, code, 1, 0)
     tensors = [_c(t) for t in (w, A_K, C_K, m_pred, a, mask, eps_z, L_Q, eps_a, L_R)]
     a_w = torch.empty(B, p, dtype=a.dtype, device=a.device)
@@ -558,7 +697,7 @@ def masked_mlp_fits(hidden, p, K, dtype):
 
 @torch.no_grad()
 def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z=None, L_Q=None,
-                      eps_a=None, L_R=None, symmetrize=True):
+                      eps_a=None, L_R=None, symmetrize=True, first_weights=None):
     """The masked filter (kvae/state_space_model.py:219-352) with a two-layer perceptron
     weight network evaluated inside the recursion: one launch for all T steps, values
     only.  Returns (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs, a_w,
@@ -568,12 +707,38 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
         _c, (a, mask, packed, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R))
     T, B, p = a.shape
     K, n = A_K.shape[0], A_K.shape[1]
+    dims2 = embedding_dims(n, p, K, a.dtype)
+    if dims2 is None:
+        return None
+    if dims2 != (n, p, K):
+        # the same recursion on the padded problem: zero columns for the extra inputs of
+        # the network, and extra outputs whose softmax weight is exactly zero
+        e = _Embedding(n, p, K, *dims2)
+        units = packed[:hidden * (p + 1 + K)].view(hidden, p + 1 + K)
+        units = torch.cat([e.vec_p(units[:, :p]), units[:, p:p + 1], e.weights(units[:, p + 1:])],
+                          dim=1)
+        off = packed.new_full((e.dK,), -1e30)
+        packed2 = torch.cat([units.reshape(-1), packed[hidden * (p + 1 + K):], off])
+        if not masked_mlp_fits(hidden, e.p2, e.K2, a.dtype):
+            return None
+        out = masked_filter_mlp(e.vec_p(a), mask, packed2, hidden, e.bases_A(A_K),
+                                e.bases_C(C_K), e.cov_n(Q), e.cov_p(R), e.vec_n(m_in),
+                                e.cov_n(P_in), e.vec_n(eps_z), e.cov_n(L_Q), e.vec_p(eps_a),
+                                e.cov_p(L_R), symmetrize=symmetrize, first_weights=K)
+        if out is None:
+            return None
+        m, P, mn, Pn, As, Cs, a_w, alpha = out
+        return (e.cut_n(m), e.cut_nn(P), e.cut_n(mn), e.cut_nn(Pn), e.cut_nn(As), e.cut_pn(Cs),
+                e.cut_p(a_w), e.cut_K(alpha))
     dims = _dims(T, B, n, p, K, a.dtype, symmetrize, 0)
     new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
     m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
     As, Cs, a_w = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p)
     alpha = new(T + 1, B, K)
-    alpha[0] = 1.0 / K
+    # the first step mixes with uniform weights over the real bases
+    first = first_weights or K
+    alpha[0] = 0.0
+    alpha[0, :, :first] = 1.0 / first
     io = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
                    m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2),
                    mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs,
@@ -590,24 +755,55 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
 
 def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,
                         want_mats=True):
-    return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,
-                                      burn_in, want_mats)
+    e = _embedding(A_K.shape[1], a.shape[-1], A_K.shape[0], a.dtype)
+    if e.identity:
+        return KalmanFilterFunction.apply(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize,
+                                          burn_in, want_mats)
+    m, P, mn, Pn, As, Cs = KalmanFilterFunction.apply(
+        e.vec_p(a), e.weights(alpha), mask, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q),
+        e.cov_p(R), e.vec_n(m_in), e.cov_n(P_in), symmetrize, burn_in, want_mats)
+    if want_mats:
+        As, Cs = e.cut_nn(As), e.cut_pn(Cs)
+    return e.cut_n(m), e.cut_nn(P), e.cut_n(mn), e.cut_nn(Pn), As, Cs
 
 
 def kalman_smooth_steps(m, P, mn, Pn, As, Cs, LR=None, eps_state=None, eps_obs=None,
                         symmetrize=True, burn_in=0):
-    return KalmanSmoothFunction.apply(m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs, symmetrize,
-                                      burn_in)
+    e = _embedding(m.shape[-1], Cs.shape[-2], None, m.dtype)
+    if e.identity:
+        return KalmanSmoothFunction.apply(m, P, mn, Pn, As, Cs, LR, eps_state, eps_obs,
+                                          symmetrize, burn_in)
+    ms, Ps, zs, ares = KalmanSmoothFunction.apply(
+        e.vec_n(m), e.cov_n(P), e.vec_n(mn), e.cov_n(Pn), e.mat_nn(As), e.mat_pn(Cs), e.cov_p(LR),
+        e.vec_n(eps_state), e.vec_p(eps_obs), symmetrize, burn_in)
+    return e.cut_n(ms), e.cut_nn(Ps), e.cut_n(zs), e.cut_p(ares)
+
+
+def _elbo_operands(e, a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
+    return (e.vec_p(a), e.vec_n(ms), e.cov_n(Ps), e.mat_nn(As), e.mat_pn(Cs), e.cov_n(Q),
+            e.cov_p(R), e.vec_n(m0), e.cov_n(P0), e.vec_n(eps))
 
 
 def kalman_elbo_terms(a, ms, Ps, As, Cs, Q, R, m0, P0, eps):
-    return KalmanElboFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+    e = _embedding(ms.shape[-1], a.shape[-1], None, a.dtype)
+    if e.identity:
+        return KalmanElboFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps)
+    obs, trans, post, z = KalmanElboFunction.apply(
+        *_elbo_operands(e, a, ms, Ps, As, Cs, Q, R, m0, P0, eps))
+    return obs + e.c_obs, trans + e.c_lat, post + e.c_lat, e.cut_n(z)
 
 
 def kalman_elbo_objective(a, ms, Ps, As, Cs, Q, R, m0, P0, eps, w_obs, w_trans, w_post):
     """(objective, weighted totals (3,), terms (3,T,B), z): see KalmanElboObjectiveFunction."""
-    return KalmanElboObjectiveFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps, float(w_obs),
-                                             float(w_trans), float(w_post))
+    w = (float(w_obs), float(w_trans), float(w_post))
+    e = _embedding(ms.shape[-1], a.shape[-1], None, a.dtype)
+    if e.identity:
+        return KalmanElboObjectiveFunction.apply(a, ms, Ps, As, Cs, Q, R, m0, P0, eps, *w)
+    objective, weighted, terms, z = KalmanElboObjectiveFunction.apply(
+        *_elbo_operands(e, a, ms, Ps, As, Cs, Q, R, m0, P0, eps), *w)
+    objective, weighted, terms = _shift_totals(
+        objective, weighted, terms, a.shape[0] * a.shape[1], ((e.c_obs, e.c_lat, e.c_lat), w), a)
+    return objective, weighted, terms, e.cut_n(z)
 
 
 @torch.no_grad()
@@ -617,6 +813,20 @@ def kalman_filter_smooth_nograd(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR=N
     (inference / imputation: no autograd graph is recorded).  Returns
     (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs,
      mean_smooth, cov_smooth, zs, as_resampled)."""
+    e = _embedding(A_K.shape[1], a.shape[-1], A_K.shape[0], a.dtype)
+    if e.identity:
+        return _filter_smooth_native(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state,
+                                     eps_obs, symmetrize)
+    m, P, mn, Pn, As, Cs, ms, Ps, zs, ares = _filter_smooth_native(
+        e.vec_p(a), e.weights(alpha), mask, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q),
+        e.cov_p(R), e.vec_n(m_in), e.cov_n(P_in), e.cov_p(LR), e.vec_n(eps_state),
+        e.vec_p(eps_obs), symmetrize)
+    return (e.cut_n(m), e.cut_nn(P), e.cut_n(mn), e.cut_nn(Pn), e.cut_nn(As), e.cut_pn(Cs),
+            e.cut_n(ms), e.cut_nn(Ps), e.cut_n(zs), e.cut_p(ares))
+
+
+def _filter_smooth_native(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs,
+                          symmetrize):
     capi.require_gpu(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs)
     a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs = map(
         _c, (a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, LR, eps_state, eps_obs))

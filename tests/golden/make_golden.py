@@ -195,8 +195,9 @@ def build_case(ref, name, cfg):
     data["out.agg_trans"] = _np(info["kalman_state_transition_log_likelihood"])
     data["out.agg_post"] = _np(info["kalman_posterior_log_likelihood"])
     data["out.objective"] = _np(objective)
-    for k in out_names:
-        data["cot." + k] = _np(cots[k])
+    if not cfg.get("objective_only", False):
+        for k in out_names:
+            data["cot." + k] = _np(cots[k])
     for (k, _), gval in zip(params.items(), grads):
         if gval is not None:
             data["grad." + k] = _np(gval)
@@ -291,6 +292,35 @@ def cases():
     c["train_n8_f64"] = dict(base, seed=34, n=8, p=4, K=4, T=6, B=2, net="lstm", train_mode=True,
                              state_transition="sample", observation="sample",
                              objective_only=True, burn_in=1)
+    # (z_dim, a_dim, K) without a kernel of their own: solved as a block of a larger compiled
+    # problem (the reference constructor, state_space_model.py:16-33, takes any dimensions)
+    c["embed_n5p3k4_f64"] = dict(base, seed=40, n=5, p=3, K=4, T=6, B=3, net="lstm",
+                                 mask="random", general_noise=True, learn_noise_covariance=True,
+                                 general_init=True, symmetric_init=True, train_mode=True,
+                                 state_transition="sample", observation="sample", burn_in=1)
+    c["embed_n4p2k5_f64"] = dict(base, seed=41, K=5, general_noise=True,
+                                 learn_noise_covariance=True)
+    c["embed_n4p2k1_f64"] = dict(base, seed=42, K=1, net="lstm", train_mode=True,
+                                 state_transition="sample", observation="sample", burn_in=2)
+    c["embed_n10p5k3_f64"] = dict(base, seed=43, n=10, p=5, K=3, T=5, B=2, net="lstm",
+                                  general_noise=True, learn_noise_covariance=True,
+                                  train_mode=True, state_transition="sample",
+                                  observation="sample")
+    c["embed_n2p3k2_mask_f64"] = dict(base, seed=44, n=2, p=3, K=2, mask="continuous", T=9)
+    c["train_embed_n4p2k6_f64"] = dict(tr, net="lstm", seed=45, K=6, T=10, B=3)
+    c["train_embed_n5p3k2_f64"] = dict(base, seed=46, n=5, p=3, K=2, train_mode=True,
+                                       state_transition="sample", observation="sample",
+                                       objective_only=True, burn_in=1, T=8, B=3,
+                                       general_noise=True, general_init=True,
+                                       symmetric_init=True, learn_noise_covariance=True,
+                                       sequence_operation="sum", kalman_weight=0.6)
+    # G7 at T=64: the large-state kernels over a longer recursion (float64 run stored as
+    # float32; the gradients of the objective alone keep the file small)
+    c["g7_large_T64_f64s"] = dict(base, seed=47, n=32, p=16, K=8, T=64, B=1, net="lstm",
+                                  general_noise=True, learn_noise_covariance=True,
+                                  train_mode=True, state_transition="sample",
+                                  observation="sample", burn_in=2, objective_only=True,
+                                  store_f32=True)
     return c
 
 

@@ -311,7 +311,7 @@ int welbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
 
 #define WAVE_DIM_LIST(X) X(32, 16, 8) X(16, 8, 4) X(6, 3, 2) X(4, 2, 3)
 
-#define DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(8, 4, 4)
+#define DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(8, 4, 4) X(4, 2, 8)
 #define CASE(n_, p_, K_)                                          \
     if (d->n == n_ && d->p == p_ && d->K == K_) {                 \
         if (d->dtype == KVAE_F32) return FN<float, n_, p_, K_>ARGS; \

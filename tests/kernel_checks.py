@@ -226,8 +226,8 @@ def check_loss(backend, T, B, n, p, K, dtype, seed=0, mask_kind="none", symmetri
     got = fwd["out"].double().cpu()
     if not (float((got[:3] - totals.detach()).abs().max()) < tol * float(scale.detach())):
         failures.append(f"out[0:3]: {got[:3].tolist()} vs {totals.tolist()}")
-    if not (abs(float(got[3] - totals.sum())) < tol * float(scale.detach())):
-        failures.append(f"out[3]: {float(got[3])} vs {float(totals.sum())}")
+    if not (abs(float(got[3] - totals.detach().sum())) < tol * float(scale.detach())):
+        failures.append(f"out[3]: {float(got[3])} vs {float(totals.detach().sum())}")
 
     # cotangents of the three weighted totals (stride 1) or of their total (stride 0)
     cot = torch.tensor([0.8, -1.1, 0.6], dtype=torch.float64) if stride else \

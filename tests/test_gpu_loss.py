@@ -13,7 +13,7 @@ from kernel_harness import Backend
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)]
+DIMS = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4), (4, 2, 8)]
 
 
 @pytest.fixture(scope="module")

@@ -224,7 +224,7 @@ def test_errors_match_reference():
     with pytest.raises(RuntimeError):
         ssm.kalman_filter(a.cpu(), SampleControl())  # no CPU path
     with pytest.raises(NotImplementedError):
-        StateSpaceModel(2, 5, 3, "mlp").cuda().kalman_filter(a, SampleControl())
+        StateSpaceModel(2, 40, 3, "mlp").cuda().kalman_filter(a, SampleControl())  # z_dim > 32
 
 
 def test_nonpd_is_reported():

@@ -9,7 +9,7 @@ import torch
 import kernel_checks as KC
 from kernel_harness import Backend
 
-DIMS = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)]
+DIMS = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4), (4, 2, 8)]
 
 
 @pytest.fixture(scope="module")
