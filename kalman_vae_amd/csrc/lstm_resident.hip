@@ -196,7 +196,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         float* h_tile = hbuf[t & 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int lr = 4 * s + i;
+            const int lr = 4 * s + i, row = r0 + lr;
             *reinterpret_cast<float2*>(h_tile + lr * RLDA + ub) = res[i][4];
             if (FULL || row < B) {
                 const long o = (long)row * RH + ub;
