@@ -2,10 +2,14 @@
 examples/evaluate.py:60-64 reads them): one ``torch.save`` dictionary with the
 keys ``epoch``, ``model_state_dict``, ``optimizer_state_dict``,
 ``scheduler_state_dict``, ``train_loss``, ``test_loss``.  The model here has the
-reference's parameter names, so files written by either side load on the other.
+reference's parameter names, so files written by either side load on the other;
+the reference's reader loads the optimizer and scheduler entries unconditionally
+(examples/evaluate.py:63-64), so a file written WITHOUT them (a warning is issued)
+loads only through ``load_checkpoint`` here.
 Loading uses ``weights_only=True``: nothing stored in the file is executed.
 """
 import os
+import warnings
 
 import torch
 
@@ -18,6 +22,9 @@ def save_checkpoint(checkpoint_dir, epoch, model, optimizer=None, scheduler=None
     """Writes ``<checkpoint_dir>/state-<epoch>.pth`` and returns its path."""
     os.makedirs(checkpoint_dir, exist_ok=True)
     path = os.path.join(checkpoint_dir, f"state-{epoch}.pth")
+    if optimizer is None or scheduler is None:
+        warnings.warn("checkpoint without optimizer / scheduler state: the reference's "
+                      "evaluate.py cannot read it (it loads both unconditionally)")
     torch.save({
         "epoch": epoch,
         "model_state_dict": model.state_dict(),

@@ -59,12 +59,14 @@ def kalman_elbo(
         flat = _standard_normal((sum(sizes),), dtype=as_.dtype, device=as_.device)
         pieces = [piece.view(shape) for piece, shape in zip(flat.split(sizes), shapes)]
         ssm._noise_pool, eps = pieces[:-1], pieces[-1]
+    ssm._defer_status = True       # one blocking read of the status word, at the end
     try:
         return _kalman_elbo(ssm, as_, sample_control, observation_mask, kalman_weight,
                             learn_weight_model, symmetrize_covariance, burn_in,
                             sequence_operation, batch_operation, eps)
     finally:
         ssm._noise_pool = None
+        ssm._defer_status = False
 
 
 def _kalman_elbo_fused(ssm, as_, sample_control, kalman_weight, learn_weight_model,

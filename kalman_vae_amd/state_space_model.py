@@ -86,6 +86,7 @@ class StateSpaceModel(nn.Module):
         # behaviour switches that have no counterpart in the reference
         self._matrix_cache = None   # see cached_matrices()
         self._noise_pool = None     # see _draw()
+        self._defer_status = False  # kalman_elbo reads the status word once per step
         self.rng_parity = True      # draw noise exactly like the reference does
         # kalman_elbo: compute the objective with the one-launch-per-direction kernels that
         # never materialise the filter / smoother tensors (info then holds None for them)
@@ -206,7 +207,9 @@ class StateSpaceModel(nn.Module):
         return _standard_normal(shape, dtype=like.dtype, device=like.device)
 
     def _finish(self, device):
-        if self.check_numerics:
+        # the status bits are OR-accumulated on the device: a caller that runs several
+        # ops (kalman_elbo) defers the one blocking read to its end
+        if self.check_numerics and not self._defer_status:
             F.raise_on_status(device)
 
     # -- filter (state_space_model.py:172-373) ---------------------------------

@@ -58,3 +58,14 @@ def rel_err(x, ref):
     ref = ref.detach().double().cpu()
     scale = ref.abs().max().clamp_min(1e-30)
     return float((x - ref).abs().max() / scale)
+
+
+def seeded_tensor(name, shape, seed, bound):
+    """A float32-representable tensor that depends only on (name, shape, seed): uniform in
+    (-bound, bound) from numpy's frozen legacy generator.  Lets a fixture leave out large
+    parameter tensors: the script that made it and the test that replays it both call
+    this."""
+    import zlib
+    rs = np.random.RandomState((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 32))
+    v = rs.uniform(-bound, bound, size=tuple(shape)).astype(np.float32)
+    return torch.from_numpy(v)

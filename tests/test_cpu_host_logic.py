@@ -206,6 +206,15 @@ def test_checkpoint_layout_round_trip(tmp_path):
     for a, b in zip(m1.state_dict().values(), m2.state_dict().values()):
         assert torch.equal(a, b)
     assert s2.last_epoch == s1.last_epoch and o2.state_dict()["state"].keys() == o1.state_dict()["state"].keys()
+    # read the file the way the reference's evaluate.py:60-64 does: all three unconditionally
+    m4, o4, s4 = make()
+    ck = torch.load(path, weights_only=True)
+    m4.load_state_dict(ck["model_state_dict"])
+    o4.load_state_dict(ck["optimizer_state_dict"])
+    s4.load_state_dict(ck["scheduler_state_dict"])
+    assert s4.last_epoch == s1.last_epoch
+    with pytest.warns(UserWarning, match="optimizer"):
+        save_checkpoint(str(tmp_path / "bare"), 1, m1)
 
     # a file in the reference's layout whose state_dict came from the reference's module
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "kvae", "gaussian_lstm_f64.npz"))
