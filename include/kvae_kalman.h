@@ -308,6 +308,45 @@ typedef struct kvae_masked_mlp {
 int kvae_filter_forward_masked_mlp(const kvae_dims *d, const kvae_filter_fwd *io,
                                    const kvae_masked_mlp *net, void *stream);
 
+/* Open-loop rollout past the end of a filtered sequence: StateSpaceModel.predict_future,
+ * kvae/state_space_model.py:486-575.  d->T is the number of NEW steps S written by the
+ * call; B, n, p, K, dtype as usual.  Per new step, from the last one-step prediction
+ * (mean_pred, cov_pred) and the last mixed observation matrix mat_C (= mat_Cs[T]):
+ *   emit:    means <- mean_pred, covs <- cov_pred; z = mean_pred (+ chol(cov_pred) eps when
+ *            `sample`, :526-533); a = mat_C z (:541)
+ *   weights: w = net(a) (:544)
+ *   advance: A = sum_k w_k A_K[k], C likewise (:545-548); mean_pred <- A mean_pred (:549);
+ *            cov_pred <- sym(Q) when `sample`, else sym(A cov_pred A^T + Q) (:550-563)
+ * phase KVAE_ROLLOUT_ALL: all S steps in one launch with the two-layer perceptron
+ *   `packed_mlp` (layout of kvae_masked_mlp.packed, `hidden` units, must fit 16 KB)
+ *   evaluated in the loop.
+ * phase KVAE_ROLLOUT_EMIT / KVAE_ROLLOUT_ADVANCE (S must be 1): the two halves of one step
+ *   for a caller that runs a recurrent weight network in between; ADVANCE reads the
+ *   weights of the new step from `alpha` (B,K).
+ * Values only.  Small state dimensions (KVAE_E_UNSUPPORTED otherwise).  A covariance that
+ * is not positive definite when sampled sets bit 2 of *status.                         */
+enum { KVAE_ROLLOUT_ALL = 0, KVAE_ROLLOUT_EMIT = 1, KVAE_ROLLOUT_ADVANCE = 2 };
+
+typedef struct kvae_rollout {
+    const void *A_K, *C_K, *Q;   /* (K,n,n), (K,p,n), (n,n) */
+    const void *mean_pred;       /* (B,n)   m_{T|T-1}, the last row of the filter's mean_pred */
+    const void *cov_pred;        /* (B,n,n) */
+    const void *mat_C;           /* (B,p,n) the last row of mat_Cs; unused by ADVANCE */
+    const void *eps;             /* (S,B,n) standard-normal draws; NULL unless `sample` */
+    const void *packed_mlp;      /* ALL only */
+    const void *alpha;           /* (B,K), ADVANCE only */
+    int32_t hidden, phase, sample, _pad;
+    void *as_new;                /* out (S,B,p)   the generated observations */
+    void *means, *covs;          /* out (S,B,n), (S,B,n,n): rows appended to means / covariances */
+    void *mean_pred_new;         /* out (S,B,n)   rows appended to next_means */
+    void *cov_pred_new;          /* out (S,B,n,n) */
+    void *mat_As_new;            /* out (S,B,n,n) rows appended to mat_As */
+    void *mat_Cs_new;            /* out (S,B,p,n) */
+    int32_t *status;
+} kvae_rollout;
+
+int kvae_predict_future(const kvae_dims *d, const kvae_rollout *io, void *stream);
+
 /* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
  * (and of the imputation path kvae/evaluation.py:100-140): runs
  * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream`.

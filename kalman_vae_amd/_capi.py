@@ -68,6 +68,12 @@ LossBwd = _ptr_struct("LossBwd", [
     "d_a", "d_alpha", "d_A_K", "d_C_K", "d_Q", "d_R", "d_m0", "d_P0"])
 MaskedMlp = _ptr_struct("MaskedMlp", [
     ("hidden", C.c_int32), ("_pad", C.c_int32), "packed", "eps_z", "L_Q", "eps_a", "L_R", "a_w"])
+Rollout = _ptr_struct("Rollout", [
+    "A_K", "C_K", "Q", "mean_pred", "cov_pred", "mat_C", "eps", "packed_mlp", "alpha",
+    ("hidden", C.c_int32), ("phase", C.c_int32), ("sample", C.c_int32), ("_pad", C.c_int32),
+    "as_new", "means", "covs", "mean_pred_new", "cov_pred_new", "mat_As_new", "mat_Cs_new",
+    "status"])
+ROLLOUT_ALL, ROLLOUT_EMIT, ROLLOUT_ADVANCE = 0, 1, 2
 
 EXPORTS = (
     "kvae_version", "kvae_error_string", "kvae_supported", "kvae_workspace_bytes",
@@ -77,7 +83,7 @@ EXPORTS = (
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
     "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_loss_saved_bytes",
     "kvae_loss_supported",
-    "kvae_filter_forward_masked_mlp",
+    "kvae_filter_forward_masked_mlp", "kvae_predict_future",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
@@ -203,6 +209,8 @@ def load():
     lib.kvae_filter_forward_masked_mlp.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd),
                                                    C.POINTER(MaskedMlp), _vp]
     lib.kvae_filter_forward_masked_mlp.restype = C.c_int
+    lib.kvae_predict_future.argtypes = [C.POINTER(Dims), C.POINTER(Rollout), _vp]
+    lib.kvae_predict_future.restype = C.c_int
     lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
     lib.kvae_lstm2_prepare.restype = C.c_int
     lib.kvae_lstm2_prepared_elems.argtypes = []

@@ -504,6 +504,37 @@ KV_HD void filter_forward_sequence(const FilterFwdArgs<R>& g, int b) {
 // `net` is the packed network: per hidden unit j the P entries of W1[j], b1[j] and
 // the K entries of W2[:, j]; then b2.  a_w (T,B,P) and rows 1..T of alpha_out
 // (T+1,B,K) are written; row 0 of alpha_out holds the weights of the first step.
+// softmax(W2 relu(W1 a + b1) + b2) from the packed network: per hidden unit j the P
+// entries of W1[j], b1[j] and the K entries of W2[:, j]; then b2
+// (dynamics_parameter_network.py:61-90 with num_layers = 2).
+template <typename R, int P, int K>
+KV_HD void mlp2_softmax(const R* net, int hidden, const R* a, R* w) {
+    constexpr int UNIT = P + 1 + K;
+    R logit[K];
+    KV_UNROLL
+    for (int k = 0; k < K; ++k) logit[k] = net[(long)hidden * UNIT + k];
+    for (int j = 0; j < hidden; ++j) {
+        const R* u = net + (long)j * UNIT;
+        R h = u[P];
+        KV_UNROLL
+        for (int i = 0; i < P; ++i) h += u[i] * a[i];
+        h = h > R(0) ? h : R(0);
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) logit[k] += u[P + 1 + k] * h;
+    }
+    R top = logit[0];
+    KV_UNROLL
+    for (int k = 1; k < K; ++k) top = logit[k] > top ? logit[k] : top;
+    R total = R(0);
+    KV_UNROLL
+    for (int k = 0; k < K; ++k) {
+        w[k] = exp(logit[k] - top);
+        total += w[k];
+    }
+    KV_UNROLL
+    for (int k = 0; k < K; ++k) w[k] /= total;
+}
+
 template <typename R>
 struct MaskedNetArgs {
     int hidden;
@@ -516,7 +547,6 @@ template <typename R, int N, int P, int K>
 KV_HD void filter_forward_masked_mlp_sequence(const FilterFwdArgs<R>& g,
                                               const MaskedNetArgs<R>& q, int b) {
     const long B = g.B;
-    constexpr int UNIT = P + 1 + K;
     filter_forward_loop<R, N, P, K>(
         g, b, [&](int, long tb, const R* w, const R* C, const R* mp, const R* a, R* wn) {
             R A[N * N], z[N], aw[P];
@@ -539,29 +569,7 @@ KV_HD void filter_forward_masked_mlp_sequence(const FilterFwdArgs<R>& g,
             KV_UNROLL
             for (int i = 0; i < P; ++i) aw[i] = mu * a[i] + (R(1) - mu) * aw[i];
             gstore<R, P>(q.a_w + tb * P, aw);
-            R logit[K];
-            KV_UNROLL
-            for (int k = 0; k < K; ++k) logit[k] = q.net[(long)q.hidden * UNIT + k];
-            for (int j = 0; j < q.hidden; ++j) {
-                const R* u = q.net + (long)j * UNIT;
-                R h = u[P];
-                KV_UNROLL
-                for (int i = 0; i < P; ++i) h += u[i] * aw[i];
-                h = h > R(0) ? h : R(0);
-                KV_UNROLL
-                for (int k = 0; k < K; ++k) logit[k] += u[P + 1 + k] * h;
-            }
-            R top = logit[0];
-            KV_UNROLL
-            for (int k = 1; k < K; ++k) top = logit[k] > top ? logit[k] : top;
-            R total = R(0);
-            KV_UNROLL
-            for (int k = 0; k < K; ++k) {
-                wn[k] = exp(logit[k] - top);
-                total += wn[k];
-            }
-            KV_UNROLL
-            for (int k = 0; k < K; ++k) wn[k] /= total;
+            mlp2_softmax<R, P, K>(q.net, q.hidden, aw, wn);
             gstore<R, K>(q.alpha_out + (tb + B) * K, wn);
         });
 }

@@ -690,6 +690,17 @@ def pack_mlp2(first, last):
     return torch.cat([units.reshape(-1), last.bias]).detach().contiguous()
 
 
+def _pad_packed_mlp(e, packed, hidden):
+    """The packed perceptron of an (n, p, K) problem for its embedding ``e``: zero columns
+    for the extra inputs, and extra outputs whose softmax weight is exactly zero."""
+    p, K = e.p, e.K
+    units = packed[:hidden * (p + 1 + K)].view(hidden, p + 1 + K)
+    units = torch.cat([e.vec_p(units[:, :p]), units[:, p:p + 1], e.weights(units[:, p + 1:])],
+                      dim=1)
+    off = packed.new_full((e.dK,), -1e30)
+    return torch.cat([units.reshape(-1), packed[hidden * (p + 1 + K):], off]).contiguous()
+
+
 def masked_mlp_fits(hidden, p, K, dtype):
     """Whether the packed two-layer network fits the 16 KB the kernel stages it in."""
     return (hidden * (p + 1 + K) + K) * torch.empty((), dtype=dtype).element_size() <= 16 * 1024
@@ -714,11 +725,7 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
         # the same recursion on the padded problem: zero columns for the extra inputs of
         # the network, and extra outputs whose softmax weight is exactly zero
         e = _Embedding(n, p, K, *dims2)
-        units = packed[:hidden * (p + 1 + K)].view(hidden, p + 1 + K)
-        units = torch.cat([e.vec_p(units[:, :p]), units[:, p:p + 1], e.weights(units[:, p + 1:])],
-                          dim=1)
-        off = packed.new_full((e.dK,), -1e30)
-        packed2 = torch.cat([units.reshape(-1), packed[hidden * (p + 1 + K):], off])
+        packed2 = _pad_packed_mlp(e, packed, hidden)
         if not masked_mlp_fits(hidden, e.p2, e.K2, a.dtype):
             return None
         out = masked_filter_mlp(e.vec_p(a), mask, packed2, hidden, e.bases_A(A_K),
@@ -751,6 +758,68 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
         return None
     capi.check(rc)
     return m, P, mn, Pn, As, Cs, a_w, alpha
+
+
+def rollout_supported(n, p, K, dtype):
+    """Whether kvae_predict_future has a kernel for these dimensions, directly or as a
+    block of a larger compiled problem (small state dimensions only)."""
+    dims = embedding_dims(n, p, K, dtype, fused=True)   # the lane-per-sequence shapes
+    return dims is not None
+
+
+@torch.no_grad()
+def predict_rollout(phase, A_K, C_K, Q, mean_pred, cov_pred, mat_C=None, eps=None, packed=None,
+                    hidden=0, alpha=None, sample=False, steps=1):
+    """kvae_predict_future (kvae/state_space_model.py:486-575), values only.
+    phase "all": every new step in one launch with the packed two-layer perceptron
+    evaluated in the loop; returns (as_new (S,B,p), means, covs, mean_pred_new, cov_pred_new,
+    mat_As_new, mat_Cs_new), each with S rows.  phase "emit": (as_new, means, covs) of one
+    step; phase "advance": (mean_pred_new, cov_pred_new, mat_As_new, mat_Cs_new) of one step
+    from the weights ``alpha`` (B,K)."""
+    capi.require_gpu(A_K, C_K, Q, mean_pred, cov_pred, mat_C, eps, packed, alpha)
+    K, n = A_K.shape[0], A_K.shape[1]
+    p = C_K.shape[1]
+    B = mean_pred.shape[0]
+    dims2 = embedding_dims(n, p, K, mean_pred.dtype, fused=True)
+    if dims2 is None:
+        raise NotImplementedError(f"no rollout kernel covers z_dim={n}, a_dim={p}, K={K}")
+    if dims2 != (n, p, K):
+        e = _Embedding(n, p, K, *dims2)
+        if packed is not None:
+            packed = _pad_packed_mlp(e, packed, hidden)
+        out = predict_rollout(phase, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q),
+                              e.vec_n(mean_pred), e.cov_n(cov_pred), e.mat_pn(mat_C),
+                              e.vec_n(eps), packed, hidden, e.weights(alpha), sample, steps)
+        cut = {"all": (e.cut_p, e.cut_n, e.cut_nn, e.cut_n, e.cut_nn, e.cut_nn, e.cut_pn),
+               "emit": (e.cut_p, e.cut_n, e.cut_nn),
+               "advance": (e.cut_n, e.cut_nn, e.cut_nn, e.cut_pn)}[phase]
+        return tuple(f(t) for f, t in zip(cut, out))
+    S = int(steps) if phase == "all" else 1
+    dt, dev = mean_pred.dtype, mean_pred.device
+    A_K, C_K, Q, mean_pred, cov_pred, mat_C, eps, packed, alpha = map(
+        _c, (A_K, C_K, Q, mean_pred, cov_pred, mat_C, eps, packed, alpha))
+    new = lambda *s: torch.empty(s, dtype=dt, device=dev)
+    emits, advances = phase != "advance", phase != "emit"
+    as_new = new(S, B, p) if emits else None
+    means, covs = (new(S, B, n), new(S, B, n, n)) if emits else (None, None)
+    mn2, Pn2 = (new(S, B, n), new(S, B, n, n)) if advances else (None, None)
+    As2, Cs2 = (new(S, B, n, n), new(S, B, p, n)) if advances else (None, None)
+    dims = capi.Dims(S, B, n, p, K, capi.dtype_code(dt), 1, 0)
+    io = capi.fill(capi.Rollout(), A_K=A_K, C_K=C_K, Q=Q, mean_pred=mean_pred, cov_pred=cov_pred,
+                   mat_C=mat_C, eps=eps if sample else None, packed_mlp=packed, alpha=alpha,
+                   hidden=int(hidden),
+                   phase={"all": capi.ROLLOUT_ALL, "emit": capi.ROLLOUT_EMIT,
+                          "advance": capi.ROLLOUT_ADVANCE}[phase],
+                   sample=int(bool(sample)), as_new=as_new, means=means, covs=covs,
+                   mean_pred_new=mn2, cov_pred_new=Pn2, mat_As_new=As2, mat_Cs_new=Cs2,
+                   status=status_word(dev))
+    capi.check(capi.load().kvae_predict_future(C.byref(dims), C.byref(io),
+                                               capi.current_stream_ptr()))
+    if phase == "all":
+        return as_new, means, covs, mn2, Pn2, As2, Cs2
+    if phase == "emit":
+        return as_new, means, covs
+    return mn2, Pn2, As2, Cs2
 
 
 def kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, symmetrize=True, burn_in=0,

@@ -427,9 +427,16 @@ class StateSpaceModel(nn.Module):
         lists of per-step tensors.  As in the reference the weight network is fed the
         whole grown sequence at every step and keeps its cached recurrent state
         between those calls (:544; it is not cleared), and with "sample" the next
-        covariance is reset to Q (:550-551).  Plain torch ops around the weight
-        network: this is not part of the accelerated path."""
+        covariance is reset to Q (:550-551).  When no autograd graph is recorded the
+        rollout runs in the HIP library (_predict_future_kernels); otherwise as plain
+        torch ops around the weight network."""
         T, B = as_.shape[:2]
+        state_noise = wants_noise(sample_control.state_transition, "state_transition")
+        if (as_.is_cuda and not torch.is_grad_enabled() and num_steps > 0
+                and F.rollout_supported(self.z_dim, self.a_dim, self.K, as_.dtype)):
+            return self._predict_future_kernels(as_, means, covariances, next_means,
+                                                next_covariances, mat_As, mat_Cs, num_steps,
+                                                state_noise)
         as_list = list(as_)
         mat_As_list, mat_Cs_list = list(mat_As), list(mat_Cs)
         means, covariances = list(means), list(covariances)
@@ -464,3 +471,49 @@ class StateSpaceModel(nn.Module):
             next_covariances.append(next_covariance)
         return (as_tensor, means, covariances, next_means, next_covariances, mat_As_list,
                 mat_Cs_list)
+
+    def _predict_future_kernels(self, as_, means, covariances, next_means, next_covariances,
+                                mat_As, mat_Cs, num_steps, state_noise):
+        """predict_future through kvae_predict_future.  Two-layer perceptron: all new
+        steps are one launch (the network runs in the kernel).  Any other network: per
+        new step one launch emits the observation, the network runs over the grown
+        sequence from its carried state exactly as the reference does, and one launch
+        advances the prediction with the new weights."""
+        T, B = as_.shape[:2]
+        S = int(num_steps)
+        A_K, C_K, Q = self.mat_A_K, self.mat_C_K, self.mat_Q
+        mn, Pn, C_last = next_means[-1], next_covariances[-1], mat_Cs[T]
+        layers = getattr(self.weight_model, "layers", None)
+        in_kernel = (layers is not None and len(layers) == 2 and self.in_kernel_weight_network
+                     and F.masked_mlp_fits(layers[0].out_features, self.a_dim, self.K,
+                                           as_.dtype))
+        eps = None
+        if in_kernel:
+            if state_noise:
+                eps = torch.stack([self._draw((B, self.z_dim), as_) for _ in range(S)])
+            a_new, m_new, P_new, mn_new, Pn_new, As_new, Cs_new = F.predict_rollout(
+                "all", A_K, C_K, Q, mn, Pn, C_last, eps,
+                F.pack_mlp2(layers[0], layers[1]).to(as_.dtype), layers[0].out_features,
+                sample=state_noise, steps=S)
+            as_tensor = torch.cat([as_, a_new], dim=0)
+        else:
+            rows = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C")}
+            as_tensor = as_
+            for _ in range(S):
+                eps = self._draw((B, self.z_dim), as_).unsqueeze(0) if state_noise else None
+                a_s, m_s, P_s = F.predict_rollout("emit", A_K, C_K, Q, mn, Pn, C_last, eps,
+                                                  sample=state_noise)
+                as_tensor = torch.cat([as_tensor, a_s], dim=0)
+                weights = self.weight_model(as_tensor)
+                mn_s, Pn_s, A_s, C_s = F.predict_rollout("advance", A_K, C_K, Q, mn, Pn,
+                                                         alpha=weights[-1], sample=state_noise)
+                mn, Pn, C_last = mn_s[0], Pn_s[0], C_s[0]
+                for k, v in zip(("m", "P", "mn", "Pn", "A", "C"),
+                                (m_s, P_s, mn_s, Pn_s, A_s, C_s)):
+                    rows[k].append(v[0])
+            m_new, P_new, mn_new, Pn_new, As_new, Cs_new = (
+                torch.stack(rows[k]) for k in ("m", "P", "mn", "Pn", "A", "C"))
+        self._finish(as_.device)
+        return (as_tensor, list(means) + list(m_new), list(covariances) + list(P_new),
+                list(next_means) + list(mn_new), list(next_covariances) + list(Pn_new),
+                list(mat_As) + list(As_new), list(mat_Cs) + list(Cs_new))

@@ -14,6 +14,7 @@
 #include "../../include/kvae_kalman.h"
 #include "../../kalman_vae_amd/csrc/kalman_core.h"
 #include "../../kalman_vae_amd/csrc/kalman_loss.h"
+#include "../../kalman_vae_amd/csrc/kalman_rollout.h"
 #include "../../kalman_vae_amd/csrc/kalman_wave.h"
 #include <memory>
 
@@ -76,6 +77,20 @@ int masked_mlp_fwd(const kvae_dims* d, const kvae_filter_fwd* io, const kvae_mas
                        (const R*)net->L_Q, (const R*)net->eps_a,  (const R*)net->L_R,
                        (R*)net->a_w,       (R*)io->alpha};
     for (int b = 0; b < d->B; ++b) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int rollout(const kvae_dims* d, const kvae_rollout* io) {
+    RolloutArgs<R> g;
+    g.S = d->T; g.B = d->B; g.hidden = io->hidden; g.phase = io->phase; g.sample = io->sample;
+    g.A_K = (const R*)io->A_K; g.C_K = (const R*)io->C_K; g.Q = (const R*)io->Q;
+    g.mn_in = (const R*)io->mean_pred; g.Pn_in = (const R*)io->cov_pred;
+    g.C_in = (const R*)io->mat_C; g.eps = (const R*)io->eps; g.net = (const R*)io->packed_mlp;
+    g.alpha = (const R*)io->alpha;
+    g.as_new = (R*)io->as_new; g.means = (R*)io->means; g.covs = (R*)io->covs;
+    g.mn_new = (R*)io->mean_pred_new; g.Pn_new = (R*)io->cov_pred_new;
+    g.As_new = (R*)io->mat_As_new; g.Cs_new = (R*)io->mat_Cs_new; g.status = io->status;
+    for (int b = 0; b < d->B; ++b) rollout_sequence<R, N, P, K>(g, b);
     return 0;
 }
 template <typename R, int N, int P, int K>
@@ -336,6 +351,12 @@ int hostsim_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd*
 #undef FN
 #undef ARGS
 #define ARGS (d, io)
+}
+int hostsim_predict_future(const kvae_dims* d, const kvae_rollout* io) {
+#define FN rollout
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
 }
 int hostsim_filter_backward(const kvae_dims* d, const kvae_filter_bwd* io) {
 #define FN filter_bwd

@@ -187,3 +187,56 @@ def test_masked_filter_with_network_in_the_loop(n, p, K, sample):
            "weights": alpha[:T]}
     for key, val in got.items():
         assert KC.rel_err(val, want[key]) < 1e-11, key
+
+
+@pytest.mark.parametrize("case", ["mean_mlp", "sample_mlp"])
+def test_rollout_statements_match_reference(case):
+    """The rollout statements the HIP kernel compiles (kalman_rollout.h, built for the host)
+    against outputs of the reference's predict_future (tests/golden/predict/*.npz, made by
+    tests/golden/make_golden_predict.py), float64, 1e-10: all new steps in one call with the
+    two-layer perceptron evaluated in the loop."""
+    import ctypes as C
+    import os
+    import numpy as np
+    from kalman_vae_amd import _capi as capi
+    from kernel_harness import hostsim_lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = {k: torch.from_numpy(v) for k, v in
+         np.load(os.path.join(here, "golden", "predict", f"{case}_f64.npz")).items()}
+    p, n, K = (int(v) for v in d["dims"])
+    S, T, B = int(d["num_steps"]), d["as_"].shape[0], d["as_"].shape[1]
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd/")}
+    W1, b1 = sd["weight_model.layers.0.weight"], sd["weight_model.layers.0.bias"]
+    W2, b2 = sd["weight_model.layers.1.weight"], sd["weight_model.layers.1.bias"]
+    hidden = W1.shape[0]
+    packed = torch.cat([torch.cat([W1, b1.unsqueeze(1), W2.t()], dim=1).reshape(-1), b2]).contiguous()
+    Q_L = sd["_mat_Q_L"]
+    Q = (Q_L @ Q_L.T + 1e-3 * torch.eye(n, dtype=torch.float64)).contiguous()
+    new = lambda *s: torch.zeros(*s, dtype=torch.float64)
+    out = dict(as_new=new(S, B, p), means=new(S, B, n), covs=new(S, B, n, n),
+               mean_pred_new=new(S, B, n), cov_pred_new=new(S, B, n, n),
+               mat_As_new=new(S, B, n, n), mat_Cs_new=new(S, B, p, n))
+    status = torch.zeros(1, dtype=torch.int32)
+    keep = dict(A_K=sd["_mat_A_K"].contiguous(), C_K=sd["_mat_C_K"].contiguous(), Q=Q,
+                mean_pred=d["filter_next_means"][-1].contiguous(),
+                cov_pred=d["filter_next_covariances"][-1].contiguous(),
+                mat_C=d["mat_Cs"][T].contiguous(), packed_mlp=packed)
+    if "eps" in d:
+        keep["eps"] = d["eps"].contiguous()
+    io = capi.fill(capi.Rollout(), hidden=hidden, phase=capi.ROLLOUT_ALL,
+                   sample=int("eps" in d), status=status, **keep, **out)
+    dims = capi.Dims(S, B, n, p, K, capi.KVAE_F64, 1, 0)
+    lib = hostsim_lib()
+    lib.hostsim_predict_future.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.Rollout)]
+    assert lib.hostsim_predict_future(C.byref(dims), C.byref(io)) == 0
+    assert int(status) == 0
+    for got, key, skip in ((out["as_new"], "out_as", T), (out["means"], "out_means", T),
+                           (out["covs"], "out_covariances", T),
+                           (out["mean_pred_new"], "out_next_means", T),
+                           (out["cov_pred_new"], "out_next_covariances", T),
+                           (out["mat_As_new"], "out_mat_As", T + 1),
+                           (out["mat_Cs_new"], "out_mat_Cs", T + 1)):
+        want = d[key][skip:]
+        assert got.shape == want.shape, key
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 1e-10, (key, err)

@@ -1,0 +1,15 @@
+set -e
+mkdir -p gpurun_out/r02
+export TMPDIR=/tmp
+R=$PWD
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 > gpurun_out/r02/bench_prof.json 2> gpurun_out/r02/bench_prof.err
+echo trace done
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r02/pmc_f_loss -o p --output-format csv -- python3 tools/time_loss_kernels.py 4096 > gpurun_out/r02/pmc_f_loss.log 2>&1
+echo pmc1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r02/pmc_w_loss -o p --output-format csv -- python3 tools/time_loss_kernels.py 4096 > gpurun_out/r02/pmc_w_loss.log 2>&1
+echo pmc2
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r02/pmc_f_lstm -o p --output-format csv -- python3 tools/run_lstm128_once.py 4096 > gpurun_out/r02/pmc_f_lstm.log 2>&1
+echo pmc3
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r02/pmc_w_lstm -o p --output-format csv -- python3 tools/run_lstm128_once.py 4096 > gpurun_out/r02/pmc_w_lstm.log 2>&1
+echo pmc4
+find gpurun_out/r02 -name "*.csv" | head -30
