@@ -349,15 +349,34 @@ int kvae_predict_future(const kvae_dims *d, const kvae_rollout *io, void *stream
 
 /* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
  * (and of the imputation path kvae/evaluation.py:100-140): runs
- * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream`.
- * The smoother must read what the filter wrote: s->mean_filt == f->mean_filt,
- * s->cov_filt == f->cov_filt, s->mean_pred == f->mean_pred, s->cov_pred ==
- * f->cov_pred, s->mat_As == f->mat_As, s->mat_Cs == f->mat_Cs (KVAE_E_BADARG
- * otherwise).  There is no fused backward entry point: between the two backward
- * calls the caller's autograd adds the gradients of the other consumers of
- * mat_As / mat_Cs (the ELBO terms), so they stay two calls.                    */
+ * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream` (two
+ * launches, every tensor written).  The smoother must read what the filter wrote:
+ * s->mean_filt == f->mean_filt, s->cov_filt == f->cov_filt, s->mean_pred ==
+ * f->mean_pred, s->cov_pred == f->cov_pred, s->mat_As == f->mat_As, s->mat_Cs ==
+ * f->mat_Cs (KVAE_E_BADARG otherwise).  There is no fused backward entry point: between
+ * the two backward calls the caller's autograd adds the gradients of the other consumers
+ * of mat_As / mat_Cs (the ELBO terms), so they stay two calls.                    */
 int kvae_filter_smooth_forward(const kvae_dims *d, const kvae_filter_fwd *f,
                                const kvae_smooth_fwd *s, void *stream);
+
+/* The same sequence (kvae/kalman_vae.py:141-160, with the weight network of masked
+ * sequences of kvae/state_space_model.py:232-282 when `net` is given) as ONE launch that
+ * writes only what the caller asks for: inference consumers such as the imputation sweeps
+ * (kvae/evaluation.py:100-140) read `net->a_w` and `s->as_resampled` and nothing else.
+ *   f: inputs as kvae_filter_forward; alpha (T+1,B,K) is read when net is NULL, otherwise
+ *      row 0 is read and rows 1..T are written as by kvae_filter_forward_masked_mlp.  Every
+ *      output of f (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs) may be NULL.
+ *   s: LR, eps_state, eps_obs as kvae_smooth_forward; its inputs mean_filt ... mat_Cs are
+ *      ignored (the reverse sweep reads what the forward sweep of the same lane produced and
+ *      re-mixes the per-step matrices from alpha); every output (mean_smooth, cov_smooth,
+ *      zs, as_resampled) may be NULL.
+ *   workspace: kvae_filter_smooth_fused_workspace_bytes(d, f) bytes, room for those of
+ *      mean_filt / cov_filt / mean_pred / cov_pred that are NULL in f (may be NULL when 0).
+ * Forward only.  Small state dimensions (KVAE_E_UNSUPPORTED otherwise: use the two calls). */
+size_t kvae_filter_smooth_fused_workspace_bytes(const kvae_dims *d, const kvae_filter_fwd *f);
+int kvae_filter_smooth_fused(const kvae_dims *d, const kvae_filter_fwd *f,
+                             const kvae_masked_mlp *net, const kvae_smooth_fwd *s,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Recurrent part of the LSTM dynamics-parameter network, one layer over a whole

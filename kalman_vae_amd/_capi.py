@@ -84,6 +84,7 @@ EXPORTS = (
     "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_loss_saved_bytes",
     "kvae_loss_supported",
     "kvae_filter_forward_masked_mlp", "kvae_predict_future",
+    "kvae_filter_smooth_fused", "kvae_filter_smooth_fused_workspace_bytes",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
@@ -211,6 +212,12 @@ def load():
     lib.kvae_filter_forward_masked_mlp.restype = C.c_int
     lib.kvae_predict_future.argtypes = [C.POINTER(Dims), C.POINTER(Rollout), _vp]
     lib.kvae_predict_future.restype = C.c_int
+    lib.kvae_filter_smooth_fused_workspace_bytes.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd)]
+    lib.kvae_filter_smooth_fused_workspace_bytes.restype = C.c_size_t
+    lib.kvae_filter_smooth_fused.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd),
+                                             C.POINTER(MaskedMlp), C.POINTER(SmoothFwd), _vp,
+                                             C.c_size_t, _vp]
+    lib.kvae_filter_smooth_fused.restype = C.c_int
     lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
     lib.kvae_lstm2_prepare.restype = C.c_int
     lib.kvae_lstm2_prepared_elems.argtypes = []

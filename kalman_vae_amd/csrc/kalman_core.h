@@ -513,7 +513,8 @@ KV_HD void mlp2_softmax(const R* net, int hidden, const R* a, R* w) {
     R logit[K];
     KV_UNROLL
     for (int k = 0; k < K; ++k) logit[k] = net[(long)hidden * UNIT + k];
-    for (int j = 0; j < hidden; ++j) {
+#pragma GCC unroll 8
+    for (int j = 0; j < hidden; ++j) {   // uniform loads: several units in flight per wait
         const R* u = net + (long)j * UNIT;
         R h = u[P];
         KV_UNROLL

@@ -334,17 +334,15 @@ int run_impute(const ImputeArgs<R>& g, hipStream_t s) {
 // Masked filter with the two-layer perceptron weight network evaluated in the loop
 // (filter_forward_masked_mlp_sequence): the whole T-step recursion of masked sequences
 // is ONE launch, where stepping the network between filter steps takes three launches
-// per time step.  The packed network (a few KB) is staged in LDS; every lane reads the
-// same entry at the same time (broadcast reads).
-constexpr int MASKED_NET_LDS_BYTES = 16 * 1024;
+// per time step.  Every lane reads the same entry of the packed network (a few KB) at the
+// same time: `net` is a read-only, non-aliased kernel argument so that those loads are
+// scalar loads (one per wavefront, served by the scalar cache) feeding SGPR operands.
+constexpr int MASKED_NET_MAX_BYTES = 16 * 1024;
 
 template <typename R, int N, int P, int K>
 __global__ void __launch_bounds__(SEQ_BLOCK)
-filter_forward_masked_mlp_kernel(FilterFwdArgs<R> g, MaskedNetArgs<R> q) {
-    __shared__ __attribute__((aligned(16))) R net[MASKED_NET_LDS_BYTES / sizeof(R)];
-    const int len = q.hidden * (P + 1 + K) + K;
-    for (int e = threadIdx.x; e < len; e += SEQ_BLOCK) net[e] = q.net[e];
-    __syncthreads();
+filter_forward_masked_mlp_kernel(FilterFwdArgs<R> g, MaskedNetArgs<R> q,
+                                 const R* __restrict__ net) {
     q.net = net;
     const int b = blockIdx.x * SEQ_BLOCK + threadIdx.x;
     if (b < g.B) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
@@ -353,14 +351,14 @@ filter_forward_masked_mlp_kernel(FilterFwdArgs<R> g, MaskedNetArgs<R> q) {
 template <typename R, int N, int P, int K>
 int run_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd* io,
                                   const kvae_masked_mlp* net, hipStream_t s) {
-    if ((size_t)(net->hidden * (P + 1 + K) + K) * sizeof(R) > (size_t)MASKED_NET_LDS_BYTES)
+    if ((size_t)(net->hidden * (P + 1 + K) + K) * sizeof(R) > (size_t)MASKED_NET_MAX_BYTES)
         return KVAE_E_UNSUPPORTED;
     FilterFwdArgs<R> g = make_args<R>(d, io);
-    MaskedNetArgs<R> q{net->hidden,          (const R*)net->packed, (const R*)net->eps_z,
+    MaskedNetArgs<R> q{net->hidden,          nullptr,               (const R*)net->eps_z,
                        (const R*)net->L_Q,   (const R*)net->eps_a,  (const R*)net->L_R,
                        (R*)net->a_w,         (R*)io->alpha};
     hipLaunchKernelGGL((filter_forward_masked_mlp_kernel<R, N, P, K>), dim3(seq_blocks(d->B)),
-                       dim3(SEQ_BLOCK), 0, s, g, q);
+                       dim3(SEQ_BLOCK), 0, s, g, q, (const R*)net->packed);
     return launch_status();
 }
 

@@ -57,11 +57,14 @@ def _first_batch(dataloader, dtype, device):
 
 @torch.no_grad()
 def _incorrect_pixels(kvae, batch, mask, sample_control):
+    # the sweeps read two tensors of the reference's elbo() call (kvae/evaluation.py:100-140):
+    # the filter's imputed observations and the smoother's re-generated ones
     T, B = batch.shape[:2]
-    _, info = kvae.elbo(xs=batch, observation_mask=mask, sample_control=sample_control)
+    _, as_ = kvae._encode(batch, sample_control)
+    imputed = kvae.state_space_model.impute(as_, sample_control, observation_mask=mask)
     result = []
-    for key in ("filter_as", "as_resampled"):
-        frames = kvae.decoder(info[key].reshape(T * B, -1)).mean.view(batch.shape)
+    for a in imputed:
+        frames = kvae.decoder(a.reshape(T * B, -1)).mean.view(batch.shape)
         result.append(float(calculate_fraction_of_incorrect_pixels(batch, frames, mask)))
     return result
 

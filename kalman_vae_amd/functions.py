@@ -760,6 +760,106 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
     return m, P, mn, Pn, As, Cs, a_w, alpha
 
 
+FILTER_SMOOTH_OUTPUTS = ("mean_filt", "cov_filt", "mean_pred", "cov_pred", "mat_As", "mat_Cs",
+                         "a_w", "alpha", "mean_smooth", "cov_smooth", "zs", "as_resampled")
+
+
+@torch.no_grad()
+def filter_smooth_fused(a, mask, A_K, C_K, Q, R, m_in, P_in, alpha=None, packed=None, hidden=0,
+                        eps_z=None, L_Q=None, eps_a=None, L_R=None, eps_state=None, eps_obs=None,
+                        symmetrize=True, want=("a_w", "as_resampled"), _first_weights=None):
+    """Filter and RTS smoother in ONE launch that writes only the tensors named in ``want``
+    (kvae_filter_smooth_fused; kvae/kalman_vae.py:141-160 as an inference consumer such as
+    kvae/evaluation.py:100-140 uses it).  Weights: ``alpha`` (T+1,B,K) given, or the packed
+    two-layer perceptron (``packed``, ``hidden``) evaluated inside the masked filter from
+    uniform first weights.  Returns a dict of the requested tensors (names as in
+    FILTER_SMOOTH_OUTPUTS; "a_w" only with the perceptron), or None when no kernel covers
+    the dimensions."""
+    capi.require_gpu(a, mask, A_K, C_K, Q, R, m_in, P_in, alpha, packed, eps_z, L_Q, eps_a, L_R,
+                     eps_state, eps_obs)
+    unknown = set(want) - set(FILTER_SMOOTH_OUTPUTS)
+    if unknown:
+        raise ValueError(f"unknown outputs {sorted(unknown)}")
+    if (alpha is None) == (packed is None):
+        raise ValueError("give either the mixing weights or the packed perceptron")
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    dims2 = embedding_dims(n, p, K, a.dtype, fused=True)     # the lane-per-sequence shapes
+    if dims2 is None:
+        return None
+    if dims2 != (n, p, K):
+        e = _Embedding(n, p, K, *dims2)
+        if packed is not None:
+            if not masked_mlp_fits(hidden, e.p2, e.K2, a.dtype):
+                return None
+            packed = _pad_packed_mlp(e, packed, hidden)
+        out = filter_smooth_fused(
+            e.vec_p(a), mask, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q), e.cov_p(R),
+            e.vec_n(m_in), e.cov_n(P_in), e.weights(alpha), packed, hidden, e.vec_n(eps_z),
+            e.cov_n(L_Q), e.vec_p(eps_a), e.cov_p(L_R), e.vec_n(eps_state), e.vec_p(eps_obs),
+            symmetrize, want, _first_weights=K)
+        if out is None:
+            return None
+        cut = {"mean_filt": e.cut_n, "cov_filt": e.cut_nn, "mean_pred": e.cut_n,
+               "cov_pred": e.cut_nn, "mat_As": e.cut_nn, "mat_Cs": e.cut_pn, "a_w": e.cut_p,
+               "alpha": e.cut_K, "mean_smooth": e.cut_n, "cov_smooth": e.cut_nn, "zs": e.cut_n,
+               "as_resampled": e.cut_p}
+        return {k: cut[k](v) for k, v in out.items()}
+    return _filter_smooth_fused_native(a, mask, A_K, C_K, Q, R, m_in, P_in, alpha, packed, hidden,
+                                       eps_z, L_Q, eps_a, L_R, eps_state, eps_obs, symmetrize,
+                                       want, _first_weights or K)
+
+
+def _filter_smooth_fused_native(a, mask, A_K, C_K, Q, R, m_in, P_in, alpha, packed, hidden, eps_z,
+                                L_Q, eps_a, L_R, eps_state, eps_obs, symmetrize, want,
+                                first_weights):
+    (a, mask, A_K, C_K, Q, R, m_in, P_in, alpha, packed, eps_z, L_Q, eps_a, L_R, eps_state,
+     eps_obs) = map(_c, (a, mask, A_K, C_K, Q, R, m_in, P_in, alpha, packed, eps_z, L_Q, eps_a,
+                         L_R, eps_state, eps_obs))
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    lib = capi.load()
+    dims = _dims(T, B, n, p, K, a.dtype, symmetrize, 0)
+    new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+    shapes = {"mean_filt": (T, B, n), "cov_filt": (T, B, n, n), "mean_pred": (T, B, n),
+              "cov_pred": (T, B, n, n), "mat_As": (T + 1, B, n, n), "mat_Cs": (T + 1, B, p, n),
+              "mean_smooth": (T, B, n), "cov_smooth": (T, B, n, n), "zs": (T, B, n),
+              "as_resampled": (T, B, p)}
+    out = {k: new(*shapes[k]) for k in want if k in shapes}
+    net = None
+    if packed is not None:
+        # the perceptron steps from uniform weights over the real bases
+        alpha = new(T + 1, B, K)
+        alpha[0] = 0.0
+        alpha[0, :, :first_weights] = 1.0 / first_weights
+        a_w = new(T, B, p)
+        net = capi.fill(capi.MaskedMlp(), hidden=int(hidden), packed=packed, eps_z=eps_z, L_Q=L_Q,
+                        eps_a=eps_a, L_R=L_R, a_w=a_w)
+        if "a_w" in want:
+            out["a_w"] = a_w
+    if "alpha" in want:
+        out["alpha"] = alpha
+    LR = L_R if eps_obs is not None else None
+    st = status_word(a.device)
+    f = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                  m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2),
+                  mean_filt=out.get("mean_filt"), cov_filt=out.get("cov_filt"),
+                  mean_pred=out.get("mean_pred"), cov_pred=out.get("cov_pred"),
+                  mat_As=out.get("mat_As"), mat_Cs=out.get("mat_Cs"), status=st)
+    s = capi.fill(capi.SmoothFwd(), LR=LR, eps_state=eps_state, eps_obs=eps_obs,
+                  mean_smooth=out.get("mean_smooth"), cov_smooth=out.get("cov_smooth"),
+                  zs=out.get("zs"), as_resampled=out.get("as_resampled"), status=st)
+    nbytes = int(lib.kvae_filter_smooth_fused_workspace_bytes(C.byref(dims), C.byref(f)))
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=a.device)
+    rc = lib.kvae_filter_smooth_fused(C.byref(dims), C.byref(f), C.byref(net) if net else None,
+                                      C.byref(s), ws.data_ptr(), nbytes,
+                                      capi.current_stream_ptr())
+    if rc == -2:      # KVAE_E_UNSUPPORTED
+        return None
+    capi.check(rc)
+    return out
+
+
 def rollout_supported(n, p, K, dtype):
     """Whether kvae_predict_future has a kernel for these dimensions, directly or as a
     block of a larger compiled problem (small state dimensions only)."""

@@ -325,17 +325,7 @@ class StateSpaceModel(nn.Module):
         two-layer perceptron: ONE launch for the whole sequence, the network evaluated
         inside the recursion.  The noise is drawn in the order of the step-by-step path
         (per step: state, then observation).  None when no kernel covers the shapes."""
-        T, B = as_.shape[:2]
-        eps_z = eps_a = None
-        if state_noise or obs_noise:
-            ez, ea = [], []
-            for _ in range(T):
-                if state_noise:
-                    ez.append(self._draw((B, self.z_dim), as_))
-                if obs_noise:
-                    ea.append(self._draw((B, self.a_dim), as_))
-            eps_z = torch.stack(ez) if state_noise else None
-            eps_a = torch.stack(ea) if obs_noise else None
+        eps_z, eps_a = self._filter_draws(as_, state_noise, obs_noise)
         out = F.masked_filter_mlp(
             as_, mask, F.pack_mlp2(layers[0], layers[1]).to(as_.dtype), layers[0].out_features,
             self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R, self.initial_state_mean,
@@ -344,7 +334,7 @@ class StateSpaceModel(nn.Module):
         if out is None:
             return None
         m, P, mn, Pn, As, Cs, a_w, alpha = out
-        return m, P, mn, Pn, As, Cs, a_w, alpha[:T]
+        return m, P, mn, Pn, As, Cs, a_w, alpha[:as_.shape[0]]
 
     def _filter_masked_inference(self, as_, mask, state_noise, obs_noise, symmetrize, w, m_pred,
                                  P_pred, L_Q, L_R):
@@ -377,6 +367,99 @@ class StateSpaceModel(nn.Module):
         st = {k: torch.stack(v) for k, v in out.items()}
         return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
 
+    def _filter_draws(self, as_, state_noise, obs_noise):
+        """(eps_z (T,B,n), eps_a (T,B,p)) of the masked filter's imputation, drawn in the
+        order of the step-by-step path (per step: state, then observation); None where
+        the mode is "mean"."""
+        T, B = as_.shape[:2]
+        if not (state_noise or obs_noise):
+            return None, None
+        ez, ea = [], []
+        for _ in range(T):
+            if state_noise:
+                ez.append(self._draw((B, self.z_dim), as_))
+            if obs_noise:
+                ea.append(self._draw((B, self.a_dim), as_))
+        return (torch.stack(ez) if state_noise else None, torch.stack(ea) if obs_noise else None)
+
+    def _smoother_draws(self, as_, state_noise, obs_noise):
+        """(eps_state (T,B,n), eps_obs (T,B,p)) of the smoother's samples; None where the
+        mode is "mean"."""
+        T, B = as_.shape[:2]
+        eps_state = eps_obs = None
+        if self.rng_parity and (state_noise or obs_noise):
+            # draw order of the reference: t = T-1 .. 0, state then observation
+            es, eo = [None] * T, [None] * T
+            for t in reversed(range(T)):
+                if state_noise:
+                    es[t] = self._draw((B, self.z_dim), as_)
+                if obs_noise:
+                    eo[t] = self._draw((B, self.a_dim), as_)
+            eps_state = torch.stack(es) if state_noise else None
+            eps_obs = torch.stack(eo) if obs_noise else None
+        else:
+            if state_noise:
+                eps_state = self._draw((T, B, self.z_dim), as_)
+            if obs_noise:
+                eps_obs = self._draw((T, B, self.a_dim), as_)
+        return eps_state, eps_obs
+
+    @torch.no_grad()
+    def impute(self, as_, sample_control: SampleControl, observation_mask=None,
+               symmetrize_covariance: bool = True):
+        """``(filter_as, as_resampled)``: the two tensors an imputation consumer reads from
+        ``kalman_filter`` followed by ``kalman_smooth`` (kvae/kalman_vae.py:141-160 as
+        kvae/evaluation.py:100-140 uses it) - the observations with the masked steps filled
+        in by the filter, and the observations re-generated from the smoothed states.
+        With a two-layer perceptron weight network (or without a mask) the filter, the
+        network and the smoother are ONE launch that writes nothing else; otherwise the two
+        calls run.  Values only."""
+        T, B = as_.shape[:2]
+        f_state, f_obs = self._modes(sample_control, filtering=True)
+        s_state, s_obs = self._modes(sample_control, filtering=False)
+        mask = None if observation_mask is None else observation_mask.to(as_.dtype)
+        layers = getattr(self.weight_model, "layers", None)
+        in_kernel = (layers is not None and len(layers) == 2 and self.in_kernel_weight_network
+                     and F.masked_mlp_fits(layers[0].out_features, self.a_dim, self.K,
+                                           as_.dtype))
+        if (as_.is_cuda and (mask is None or in_kernel)
+                and F.rollout_supported(self.z_dim, self.a_dim, self.K, as_.dtype)):
+            self.weight_model.clear_hidden_state()
+            with self.cached_matrices():
+                common = (self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R,
+                          self.initial_state_mean, self.initial_state_covariance)
+                if mask is None:
+                    if self.rng_parity:
+                        self._filter_draws(as_, f_state, f_obs)     # drawn and unused, as the reference
+                    alpha = self.weight_model(as_, lead=True)
+                    eps_state, eps_obs = self._smoother_draws(as_, s_state, s_obs)
+                    out = F.filter_smooth_fused(
+                        as_, None, *common, alpha=alpha,
+                        L_R=self._cholesky_R() if s_obs else None, eps_state=eps_state,
+                        eps_obs=eps_obs, symmetrize=symmetrize_covariance,
+                        want=("as_resampled",))
+                    filter_as = as_
+                else:
+                    eps_z, eps_a = self._filter_draws(as_, f_state, f_obs)
+                    eps_state, eps_obs = self._smoother_draws(as_, s_state, s_obs)
+                    out = F.filter_smooth_fused(
+                        as_, mask, *common,
+                        packed=F.pack_mlp2(layers[0], layers[1]).to(as_.dtype),
+                        hidden=layers[0].out_features, eps_z=eps_z,
+                        L_Q=F.cholesky_factor(self.mat_Q) if f_state else None, eps_a=eps_a,
+                        L_R=self._cholesky_R() if (f_obs or s_obs) else None,
+                        eps_state=eps_state, eps_obs=eps_obs, symmetrize=symmetrize_covariance,
+                        want=("a_w", "as_resampled"))
+                    filter_as = out["a_w"] if out is not None else None
+            if out is not None:
+                self._finish(as_.device)
+                return filter_as, out["as_resampled"]
+        out = self.kalman_filter(as_, sample_control, observation_mask=observation_mask,
+                                 symmetrize_covariance=symmetrize_covariance)
+        smoothed = self.kalman_smooth(as_, *out[:6], sample_control=sample_control,
+                                      symmetrize_covariance=symmetrize_covariance)
+        return out[6], smoothed[3]
+
     # -- smoother (state_space_model.py:375-484) --------------------------------
     def kalman_smooth(
         self,
@@ -393,24 +476,8 @@ class StateSpaceModel(nn.Module):
     ):
         T, B, _ = as_.shape
         state_noise, obs_noise = self._modes(sample_control, filtering=False)
-        eps_state = eps_obs = L_R = None
-        if self.rng_parity and (state_noise or obs_noise):
-            # draw order of the reference: t = T-1 .. 0, state then observation
-            es, eo = [None] * T, [None] * T
-            for t in reversed(range(T)):
-                if state_noise:
-                    es[t] = self._draw((B, self.z_dim), as_)
-                if obs_noise:
-                    eo[t] = self._draw((B, self.a_dim), as_)
-            eps_state = torch.stack(es) if state_noise else None
-            eps_obs = torch.stack(eo) if obs_noise else None
-        else:
-            if state_noise:
-                eps_state = self._draw((T, B, self.z_dim), as_)
-            if obs_noise:
-                eps_obs = self._draw((T, B, self.a_dim), as_)
-        if obs_noise:
-            L_R = self._cholesky_R()
+        eps_state, eps_obs = self._smoother_draws(as_, state_noise, obs_noise)
+        L_R = self._cholesky_R() if obs_noise else None
         out = F.kalman_smooth_steps(
             filter_means, filter_covariances, filter_next_means, filter_next_covariances,
             mat_As, mat_Cs, LR=L_R, eps_state=eps_state, eps_obs=eps_obs,

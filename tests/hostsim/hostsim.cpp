@@ -15,6 +15,7 @@
 #include "../../kalman_vae_amd/csrc/kalman_core.h"
 #include "../../kalman_vae_amd/csrc/kalman_loss.h"
 #include "../../kalman_vae_amd/csrc/kalman_rollout.h"
+#include "../../kalman_vae_amd/csrc/kalman_filter_smooth.h"
 #include "../../kalman_vae_amd/csrc/kalman_wave.h"
 #include <memory>
 
@@ -77,6 +78,23 @@ int masked_mlp_fwd(const kvae_dims* d, const kvae_filter_fwd* io, const kvae_mas
                        (const R*)net->L_Q, (const R*)net->eps_a,  (const R*)net->L_R,
                        (R*)net->a_w,       (R*)io->alpha};
     for (int b = 0; b < d->B; ++b) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
+    return 0;
+}
+// every output present (the caller allocates all of them): checks the fused statements
+template <typename R, int N, int P, int K>
+int filter_smooth(const kvae_dims* d, const kvae_filter_fwd* f, const kvae_masked_mlp* net,
+                  const kvae_smooth_fwd* s) {
+    FilterSmoothArgs<R> g;
+    g.f = mk<R>(d, f);
+    g.LR = (const R*)s->LR; g.eps_s = (const R*)s->eps_state; g.eps_o = (const R*)s->eps_obs;
+    g.ms = (R*)s->mean_smooth; g.Ps = (R*)s->cov_smooth; g.zs = (R*)s->zs;
+    g.ares = (R*)s->as_resampled;
+    MaskedNetArgs<R> q{};
+    if (net)
+        q = MaskedNetArgs<R>{net->hidden,        (const R*)net->packed, (const R*)net->eps_z,
+                             (const R*)net->L_Q, (const R*)net->eps_a,  (const R*)net->L_R,
+                             (R*)net->a_w,       (R*)f->alpha};
+    for (int b = 0; b < d->B; ++b) filter_smooth_sequence<R, N, P, K>(g, net ? &q : nullptr, b);
     return 0;
 }
 template <typename R, int N, int P, int K>
@@ -346,6 +364,17 @@ int hostsim_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd*
 #define FN masked_mlp_fwd
 #undef ARGS
 #define ARGS (d, io, net)
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+#undef ARGS
+#define ARGS (d, io)
+}
+int hostsim_filter_smooth_fused(const kvae_dims* d, const kvae_filter_fwd* io,
+                                const kvae_masked_mlp* net, const kvae_smooth_fwd* s) {
+#define FN filter_smooth
+#undef ARGS
+#define ARGS (d, io, net, s)
     DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN

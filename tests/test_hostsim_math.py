@@ -240,3 +240,45 @@ def test_rollout_statements_match_reference(case):
         assert got.shape == want.shape, key
         err = float((got - want).abs().max() / want.abs().max())
         assert err < 1e-10, (key, err)
+
+
+@pytest.mark.parametrize("n,p,K", [(4, 2, 3), (3, 2, 2)])
+def test_fused_filter_smoother_statements_equal_separate_calls(n, p, K):
+    """The one-pass filter + smoother (kalman_filter_smooth.h, built for the host) against
+    the separate filter and smoother statements (pinned to the oracle by the tests above):
+    bitwise equal in float64, sampled modes, masked, every output requested."""
+    import ctypes as C
+    from kalman_vae_amd import _capi as capi
+    from kernel_harness import Backend, hostsim_lib
+    torch.manual_seed(n)
+    T, B, dt = 6, 5, torch.float64
+    r = lambda *s: torch.randn(*s, dtype=dt)
+    a, alpha = r(T, B, p), torch.softmax(r(T + 1, B, K), -1).contiguous()
+    mask = (torch.rand(T, B) < 0.7).to(dt)
+    A_K = (torch.eye(n, dtype=dt) * 0.9 + 0.05 * r(K, n, n)).contiguous()
+    C_K = 0.3 * r(K, p, n)
+    Q, R = torch.eye(n, dtype=dt) * 0.5, torch.eye(p, dtype=dt) * 0.3
+    m0, P0 = 0.1 * r(n), torch.eye(n, dtype=dt)
+    LR = torch.linalg.cholesky(R).contiguous()
+    es, eo = r(T, B, n), r(T, B, p)
+    be = Backend("hostsim")
+    f = be.filter_forward(a, alpha, mask, A_K, C_K, Q, R, m0, P0)
+    s = be.smooth_forward(f["mean_filt"], f["cov_filt"], f["mean_pred"], f["cov_pred"],
+                          f["mat_As"], f["mat_Cs"], LR, es, eo)
+    names_f = ("mean_filt", "cov_filt", "mean_pred", "cov_pred", "mat_As", "mat_Cs")
+    names_s = ("mean_smooth", "cov_smooth", "zs", "as_resampled")
+    out_f = {k: torch.full_like(f[k], float("nan")) for k in names_f}
+    out_s = {k: torch.full_like(s[k], float("nan")) for k in names_s}
+    st = torch.zeros(1, dtype=torch.int32)
+    fio = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                    m_in=m0, P_in=P0, carry_per_sequence=0, status=st, **out_f)
+    sio = capi.fill(capi.SmoothFwd(), LR=LR, eps_state=es, eps_obs=eo, status=st, **out_s)
+    lib = hostsim_lib()
+    lib.hostsim_filter_smooth_fused.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.FilterFwd),
+                                                C.c_void_p, C.POINTER(capi.SmoothFwd)]
+    d = be.dims(T, B, n, p, K, dt)
+    assert lib.hostsim_filter_smooth_fused(C.byref(d), C.byref(fio), None, C.byref(sio)) == 0
+    for k in names_f:
+        assert torch.equal(out_f[k], f[k]), k
+    for k in names_s:
+        assert torch.equal(out_s[k], s[k]), k
