@@ -543,9 +543,9 @@ def run_imputation(args, rank, world, dev, rehearsal):
         with torch.no_grad():
             if fused and args.net == "mlp":
                 # one launch per chunk: reads a, mask; writes a_w, alpha, as_resampled; the
-                # filtered / predicted moments go through the workspace once each way
+                # filtered moments go through the workspace once each way
                 tc = _timed(one_chunk, 5)
-                by = el * ((p + 1) + 2 * p + K + 2 * (2 * n + 2 * n * n)) * T * chunk
+                by = el * ((p + 1) + 2 * p + 2 * K + 2 * (n + n * n)) * T * chunk
                 res["kernels"] = {"filter_smooth_fused": {"us": tc * 1e6, "GBps": by / tc / 1e9}}
                 dom, sec = "filter_smooth_fused (one chunk, host glue included)", tc
             else:
@@ -623,7 +623,7 @@ def main():
     ap.add_argument("--state-dim", type=int, default=None)
     ap.add_argument("--obs-dim", type=int, default=None)
     ap.add_argument("--bases", type=int, default=None)
-    ap.add_argument("--chunk", type=int, default=65536, help="c3: sequences per call")
+    ap.add_argument("--chunk", type=int, default=262144, help="c3: sequences per call")
     ap.add_argument("--image", type=int, default=64, help="c5: frame height and width")
     ap.add_argument("--kernels-only", action="store_true",
                     help="time only the six separate HIP kernels with synthetic mixing weights "

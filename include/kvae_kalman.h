@@ -371,7 +371,8 @@ int kvae_filter_smooth_forward(const kvae_dims *d, const kvae_filter_fwd *f,
  *      re-mixes the per-step matrices from alpha); every output (mean_smooth, cov_smooth,
  *      zs, as_resampled) may be NULL.
  *   workspace: kvae_filter_smooth_fused_workspace_bytes(d, f) bytes, room for those of
- *      mean_filt / cov_filt / mean_pred / cov_pred that are NULL in f (may be NULL when 0).
+ *      mean_filt / cov_filt that are NULL in f (may be NULL when 0); the one-step predictions
+ *      are recomputed by the reverse sweep, not read back.
  * Forward only.  Small state dimensions (KVAE_E_UNSUPPORTED otherwise: use the two calls). */
 size_t kvae_filter_smooth_fused_workspace_bytes(const kvae_dims *d, const kvae_filter_fwd *f);
 int kvae_filter_smooth_fused(const kvae_dims *d, const kvae_filter_fwd *f,

@@ -1,7 +1,8 @@
 // kvae_filter_smooth_fused: filter (optionally with the perceptron weight network in the
 // loop) and RTS smoother of every sequence in one launch, one lane per sequence
 // (kalman_filter_smooth.h).  Outputs the caller does not ask for are not written; the
-// moments the reverse sweep reads back go through the workspace when they are not outputs.
+// filtered moments the reverse sweep reads back go through the workspace when they are not
+// outputs.
 #include "launch_common.h"
 #include "kalman_filter_smooth.h"
 
@@ -25,8 +26,6 @@ size_t filter_smooth_workspace_elems(const kvae_dims* d, const kvae_filter_fwd* 
     size_t e = 0;
     if (!f || !f->mean_filt) e += tb * n;
     if (!f || !f->cov_filt) e += tb * n * n;
-    if (!f || !f->mean_pred) e += tb * n;
-    if (!f || !f->cov_pred) e += tb * n * n;
     return e;
 }
 
@@ -52,8 +51,8 @@ int run_filter_smooth(const kvae_dims* d, const kvae_filter_fwd* f, const kvae_m
     };
     g.f.m = out_or_ws(f->mean_filt, tb * N);
     g.f.Pf = out_or_ws(f->cov_filt, tb * N * N);
-    g.f.mn = out_or_ws(f->mean_pred, tb * N);
-    g.f.Pn = out_or_ws(f->cov_pred, tb * N * N);
+    g.f.mn = (R*)f->mean_pred;     // written only when asked for: the reverse sweep
+    g.f.Pn = (R*)f->cov_pred;      // recomputes the predictions
     g.f.As = (R*)f->mat_As; g.f.Cs = (R*)f->mat_Cs; g.f.status = f->status;
     g.LR = (const R*)s->LR; g.eps_s = (const R*)s->eps_state; g.eps_o = (const R*)s->eps_obs;
     g.ms = (R*)s->mean_smooth; g.Ps = (R*)s->cov_smooth; g.zs = (R*)s->zs;

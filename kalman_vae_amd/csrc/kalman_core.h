@@ -468,8 +468,8 @@ KV_HD void filter_forward_loop(const FilterFwdArgs<R>& g, int b, Next&& next_wei
 
         gstore<R, N>(g.m + tb * N, m);
         gstore<R, N * N>(g.Pf + tb * N * N, Pf);
-        gstore<R, N>(g.mn + tb * N, mp);
-        gstore<R, N * N>(g.Pn + tb * N * N, Pp);
+        if (g.mn) gstore<R, N>(g.mn + tb * N, mp);          // null: the one-pass filter +
+        if (g.Pn) gstore<R, N * N>(g.Pn + tb * N * N, Pp);  // smoother recomputes them
         vcopy<R, K>(wn, w);
     }
     if (g.Cs) {

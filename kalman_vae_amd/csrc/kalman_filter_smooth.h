@@ -4,10 +4,12 @@
 // kvae/evaluation.py:100-140).  One lane per sequence: the forward sweep is the filter
 // loop of kalman_core.h (optionally with the perceptron weight network in the loop), the
 // reverse sweep is the statements of smooth_forward_sequence with the per-step matrices
-// re-mixed from the weights instead of read back, and every output pointer may be null.
-// The filtered / predicted moments the reverse sweep needs go through buffers that are the
-// caller's outputs where requested and a workspace otherwise; a lane reads back only what
-// it wrote itself, so the two sweeps need no synchronisation.
+// re-mixed from the weights and the one-step predictions recomputed from the filtered
+// moments (m' = A m, P' = sym(A P A^T + Q), the filter's own time update) instead of read
+// back, and every output pointer may be null.  The filtered moments the reverse sweep needs
+// go through buffers that are the caller's outputs where requested and a workspace
+// otherwise; a lane reads back only what it wrote itself, so the two sweeps need no
+// synchronisation.
 #pragma once
 
 #include "kalman_core.h"
@@ -16,7 +18,7 @@ namespace kvae {
 
 template <typename R>
 struct FilterSmoothArgs {
-    FilterFwdArgs<R> f;     // m, Pf, mn, Pn: never null (outputs or workspace); As, Cs may be
+    FilterFwdArgs<R> f;     // m, Pf: never null (outputs or workspace); mn, Pn, As, Cs may be
     const R *LR, *eps_s, *eps_o;
     R *ms, *Ps, *zs, *ares;   // each may be null
 };
@@ -63,6 +65,8 @@ KV_HD void filter_smooth_sequence(const FilterSmoothArgs<R>& g, const MaskedNetA
     } else {
         vzero<R, P * P>(LR);
     }
+    R Qm[N * N];
+    gload<R, N * N>(f.Q, Qm);
     int st = 0;
     R ms[N], Ps[N * N], C[P * N], w[K], wn[K];
     {
@@ -80,12 +84,19 @@ KV_HD void filter_smooth_sequence(const FilterSmoothArgs<R>& g, const MaskedNetA
         R m[N], Pf[N * N], mn[N], Pn[N * N], An[N * N];
         gload<R, N>(f.m + tb * N, m);
         gload<R, N * N>(f.Pf + tb * N * N, Pf);
-        gload<R, N>(f.mn + tb * N, mn);
-        gload<R, N * N>(f.Pn + tb * N * N, Pn);
         gload<R, K>(f.alpha + (tb + B) * K, wn);
         gload<R, K>(f.alpha + tb * K, w);
         mix<R, K, N * N>(wn, f.A_K, An);
         mix<R, K, P * N>(w, f.C_K, C);
+        {
+            // the time update of filter_forward_loop, again
+            R T0[N * N];
+            gemv<R, N, N, false, 0>(An, m, mn);
+            gemm<R, N, N, N, false, false, 0>(An, Pf, T0);
+            vcopy<R, N * N>(Qm, Pn);
+            gemm<R, N, N, N, false, true, 1>(T0, An, Pn);
+            if (f.symmetrize) symmetrize_inplace<R, N>(Pn);
+        }
 
         R Pi[N * N], W[N * N], J[N * N];
         if (!spd_inverse<R, N>(Pn, Pi)) st |= ST_NONPD_PREDICTED;
