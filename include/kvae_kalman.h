@@ -359,6 +359,35 @@ int kvae_predict_future(const kvae_dims *d, const kvae_rollout *io, void *stream
 int kvae_filter_smooth_forward(const kvae_dims *d, const kvae_filter_fwd *f,
                                const kvae_smooth_fwd *s, void *stream);
 
+/* Adjoint of kvae_filter_forward_masked_mlp (kvae/state_space_model.py:219-352 under
+ * autograd with an observation mask): `io` as for kvae_filter_backward, with io->fwd holding
+ * the pointers of the forward call (alpha = the weights it wrote); `net->fwd` the forward
+ * call's network arguments (a_w is read).  Per step the gradient of the weights of the next
+ * step goes on through the softmax, the perceptron, the blend a_w = mask a + (1 - mask) a_imp
+ * and the imputation a_imp = C_t (A_t m_pred + L_Q eps_z) + L_R eps_a (:232-277) into d_a,
+ * the bases, the prediction it read, and the noise factors.
+ *   g_a_w (T,B,p) / g_alpha (T+1,B,K): upstream gradients of the forward call's a_w / alpha
+ *     outputs, or NULL.
+ *   learn_weight_model 0: the weights were detached from the network (:281-282); only
+ *     g_a_w flows into the imputation.
+ *   d_logits (T,B,K): gradient w.r.t. the network's pre-softmax outputs of step t (which
+ *     became alpha[t+1]); the caller obtains the gradients of the network's parameters by
+ *     re-evaluating it on a_w and back-propagating d_logits.
+ *   d_L_Q (n,n) / d_L_R (p,p): gradients w.r.t. the noise factors of the imputation, or NULL.
+ * io->d_alpha is scratch here (the weights are internal).  Workspace:
+ * kvae_filter_backward_masked_mlp_workspace_bytes(d).  Small state dimensions only.      */
+typedef struct kvae_masked_mlp_bwd {
+    kvae_masked_mlp fwd;
+    const void *g_a_w, *g_alpha;
+    void *d_logits, *d_L_Q, *d_L_R;
+    int32_t learn_weight_model, _pad;
+} kvae_masked_mlp_bwd;
+
+size_t kvae_filter_backward_masked_mlp_workspace_bytes(const kvae_dims *d);
+int kvae_filter_backward_masked_mlp(const kvae_dims *d, const kvae_filter_bwd *io,
+                                    const kvae_masked_mlp_bwd *net, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* The same sequence (kvae/kalman_vae.py:141-160, with the weight network of masked
  * sequences of kvae/state_space_model.py:232-282 when `net` is given) as ONE launch that
  * writes only what the caller asks for: inference consumers such as the imputation sweeps

@@ -68,6 +68,9 @@ LossBwd = _ptr_struct("LossBwd", [
     "d_a", "d_alpha", "d_A_K", "d_C_K", "d_Q", "d_R", "d_m0", "d_P0"])
 MaskedMlp = _ptr_struct("MaskedMlp", [
     ("hidden", C.c_int32), ("_pad", C.c_int32), "packed", "eps_z", "L_Q", "eps_a", "L_R", "a_w"])
+MaskedMlpBwd = _ptr_struct("MaskedMlpBwd", [
+    ("fwd", MaskedMlp), "g_a_w", "g_alpha", "d_logits", "d_L_Q", "d_L_R",
+    ("learn_weight_model", C.c_int32), ("_pad", C.c_int32)])
 Rollout = _ptr_struct("Rollout", [
     "A_K", "C_K", "Q", "mean_pred", "cov_pred", "mat_C", "eps", "packed_mlp", "alpha",
     ("hidden", C.c_int32), ("phase", C.c_int32), ("sample", C.c_int32), ("_pad", C.c_int32),
@@ -85,6 +88,7 @@ EXPORTS = (
     "kvae_loss_supported",
     "kvae_filter_forward_masked_mlp", "kvae_predict_future",
     "kvae_filter_smooth_fused", "kvae_filter_smooth_fused_workspace_bytes",
+    "kvae_filter_backward_masked_mlp", "kvae_filter_backward_masked_mlp_workspace_bytes",
     "kvae_lstm_layer_forward", "kvae_lstm_layer_backward",
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
@@ -218,6 +222,11 @@ def load():
                                              C.POINTER(MaskedMlp), C.POINTER(SmoothFwd), _vp,
                                              C.c_size_t, _vp]
     lib.kvae_filter_smooth_fused.restype = C.c_int
+    lib.kvae_filter_backward_masked_mlp_workspace_bytes.argtypes = [C.POINTER(Dims)]
+    lib.kvae_filter_backward_masked_mlp_workspace_bytes.restype = C.c_size_t
+    lib.kvae_filter_backward_masked_mlp.argtypes = [C.POINTER(Dims), C.POINTER(FilterBwd),
+                                                    C.POINTER(MaskedMlpBwd), _vp, C.c_size_t, _vp]
+    lib.kvae_filter_backward_masked_mlp.restype = C.c_int
     lib.kvae_lstm2_prepare.argtypes = [_vp] * 9
     lib.kvae_lstm2_prepare.restype = C.c_int
     lib.kvae_lstm2_prepared_elems.argtypes = []

@@ -593,15 +593,25 @@ KV_HD void filter_forward_masked_mlp_sequence(const FilterFwdArgs<R>& g,
 // the gradient (written by the caller's earlier pass over the same sequence) and this
 // pass adds to them; row T of d_alpha is written.  The gradient w.r.t. the initial
 // (m_in, P_in) of the sequence is returned in m_in_bar (N) / P_in_bar (N*N).
-template <typename R, int N, int P, int K, bool ACCUM>
+// Net: NoNetAdjoint, or MlpNetAdjoint when the weights of step t+1 were produced inside the
+// filter loop by the perceptron network from the imputed observation of step t
+// (filter_forward_masked_mlp_sequence); the gradient of the weights then flows on through
+// the network into the observation, the imputation and the prediction it read.
+struct NoNetAdjoint {
+    static constexpr bool active = false;
+};
+
+template <typename R, int N, int P, int K, bool ACCUM, typename Net = NoNetAdjoint>
 KV_HD void filter_backward_core(const FilterBwdArgs<R>& g, int b, R* acc, R* m_in_bar,
-                                R* P_in_bar) {
+                                R* P_in_bar, const Net& net = Net()) {
     using PG = FilterParamGrads<N, P, K>;
     const FilterFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
     R Rm[P * P];
     gload<R, P * P>(f.Rm, Rm);
+    R At_bar[N * N];   // Net: gradient w.r.t. A_t from the imputation of step t (A_t = An of t-1)
+    vzero<R, N * N>(At_bar);
 
     R mpb[N], Ppb[N * N];  // carry: grad wrt prediction made at step t
     vzero<R, N>(mpb);
@@ -685,15 +695,41 @@ KV_HD void filter_backward_core(const FilterBwdArgs<R>& g, int b, R* acc, R* m_i
             gemm<R, N, N, N, false, false, 1>(T2, An, Pb);
             vadd<R, N * N>(Ppb, acc + PG::OFF_Q);
         }
+        const R mu = f.mask ? f.mask[tb] : R(1);
+        const R nu = R(1) - mu;
+        R Cb[P * N];
+        gload_or_zero<R, P * N>(g.g_Cs, tb * P * N, Cb);
+
+        // 2b. A-part of the mixing adjoint: d_alpha[t+1] is complete here
+        R da[K];
+        {
+            if constexpr (Net::active) vadd<R, N * N>(At_bar, Ab);   // imputation of step t+1
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) {
+                R sA = R(0);
+                KV_UNROLL
+                for (int e = 0; e < N * N; ++e) {
+                    sA += Ab[e] * f.A_K[k * N * N + e];
+                    acc[PG::OFF_A + k * N * N + e] += wn[k] * Ab[e];
+                }
+                da[k] = dwn[k] + sA;
+            }
+            if (ACCUM && t + 1 < T) {
+                KV_UNROLL
+                for (int k = 0; k < K; ++k) da[k] += g.d_alpha[(tb + B) * K + k];
+            }
+        }
+        // 2c. through the network that produced alpha[t+1] from the imputed observation
+        R a_extra[P], mp_extra[N];
+        if constexpr (Net::active) {
+            net.template step<N, P, K>(f, t, tb, da, w, wn, C, mp, mu, a_extra, Cb, At_bar, mp_extra);
+        }
+        gstore<R, K>(g.d_alpha + (tb + B) * K, da);
 
         // 3. measurement update adjoint
         UpdateTerms<R, N, P> u;
         update_terms<R, N, P>(C, mp, Pp, Rm, a, u);
-        const R mu = f.mask ? f.mask[tb] : R(1);
-        const R nu = R(1) - mu;
         if (f.symmetrize) symmetrize_inplace<R, N>(Pb);  // H
-        R Cb[P * N];
-        gload_or_zero<R, P * N>(g.g_Cs, tb * P * N, Cb);
         // new carry: gradients w.r.t. (mp, Pp)
         R mob[N], Pob[N * N];  // grads of m_obs, P_obs
         KV_UNROLL
@@ -717,6 +753,11 @@ KV_HD void filter_backward_core(const FilterBwdArgs<R>& g, int b, R* acc, R* m_i
             gload<R, P>(g.d_a + tb * P, da_t);
             KV_UNROLL
             for (int i = 0; i < P; ++i) da_t[i] += rb[i];
+            gstore<R, P>(g.d_a + tb * P, da_t);
+        } else if constexpr (Net::active) {
+            R da_t[P];
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) da_t[i] = rb[i] + a_extra[i];
             gstore<R, P>(g.d_a + tb * P, da_t);
         } else {
             gstore<R, P>(g.d_a + tb * P, rb);
@@ -751,36 +792,24 @@ KV_HD void filter_backward_core(const FilterBwdArgs<R>& g, int b, R* acc, R* m_i
             vadd<R, P * P>(Sb, acc + PG::OFF_R);
         }
 
-        // 4. mixing adjoint
-        {
-            R da[K];
+        // 4. C-part of the mixing adjoint (the C-part of d_alpha[t])
+        KV_UNROLL
+        for (int k = 0; k < K; ++k) {
+            R sC = R(0);
             KV_UNROLL
-            for (int k = 0; k < K; ++k) {
-                R sA = R(0), sC = R(0);
-                KV_UNROLL
-                for (int e = 0; e < N * N; ++e) {
-                    sA += Ab[e] * f.A_K[k * N * N + e];
-                    acc[PG::OFF_A + k * N * N + e] += wn[k] * Ab[e];
-                }
-                KV_UNROLL
-                for (int e = 0; e < P * N; ++e) {
-                    sC += Cb[e] * f.C_K[k * P * N + e];
-                    acc[PG::OFF_C + k * P * N + e] += w[k] * Cb[e];
-                }
-                da[k] = dwn[k] + sA;  // d_alpha[t+1] complete
-                dwn[k] = sC;          // C-part of d_alpha[t]
+            for (int e = 0; e < P * N; ++e) {
+                sC += Cb[e] * f.C_K[k * P * N + e];
+                acc[PG::OFF_C + k * P * N + e] += w[k] * Cb[e];
             }
-            if (ACCUM && t + 1 < T) {
-                KV_UNROLL
-                for (int k = 0; k < K; ++k) da[k] += g.d_alpha[(tb + B) * K + k];
-            }
-            gstore<R, K>(g.d_alpha + (tb + B) * K, da);
+            dwn[k] = sC;
         }
+        if constexpr (Net::active) vadd<R, N>(mp_extra, mpb);   // the imputation read mp too
     }
     // d_alpha[0]: C-part of step 0 plus <g_As[0], A^k>; A_0's basis gradient.
     {
         R gA[N * N], w0[K], da[K];
         gload_or_zero<R, N * N>(g.g_As, (long)b * N * N, gA);
+        if constexpr (Net::active) vadd<R, N * N>(At_bar, gA);   // imputation of step 0
         gload<R, K>(f.alpha + (long)b * K, w0);
         KV_UNROLL
         for (int k = 0; k < K; ++k) {
@@ -803,6 +832,105 @@ template <typename R, int N, int P, int K>
 KV_HD void filter_backward_sequence(const FilterBwdArgs<R>& g, int b, R* acc) {
     R mpb[N], Ppb[N * N];
     filter_backward_core<R, N, P, K, false>(g, b, acc, mpb, Ppb);
+    gstore<R, N>(g.d_m_in + (long)b * N, mpb);
+    gstore<R, N * N>(g.d_P_in + (long)b * N * N, Ppb);
+}
+
+// Adjoint of the in-loop perceptron and of the imputation that feeds it
+// (filter_forward_masked_mlp_sequence; state_space_model.py:232-282), per step t once the
+// gradient `da` of alpha[t+1] is complete:
+//   softmax:     dl_k = wn_k (da_k - sum_j da_j wn_j)                      -> d_logits[t]
+//   perceptron:  d a_w = sum_j W1[j,:] [pre_j > 0] sum_k W2[k,j] dl_k      (+ upstream g_a_w)
+//   blend:       d a_t += mu d a_w;   d a_imp = (1 - mu) d a_w
+//   imputation:  a_imp = C_t z (+ L_R e_a), z = A_t mp (+ L_Q e_z):
+//                Cbar_t += d a_imp z^T, d z = C_t^T d a_imp, Abar_t += d z mp^T,
+//                d mp += A_t^T d z, d L_R += d a_imp e_a^T, d L_Q += d z e_z^T
+// The gradients of the network's own parameters are left to the caller, who re-evaluates
+// the network on a_w and back-propagates d_logits (two small matrix products).
+template <typename R>
+struct MlpNetAdjoint {
+    static constexpr bool active = true;
+    MaskedNetArgs<R> q;        // forward arguments; q.a_w is read
+    const R *g_a_w, *g_alpha;  // upstream gradients (T,B,P) / (T+1,B,K), may be null
+    R* d_logits;               // (T,B,K)
+    R *acc_LQ, *acc_LR;        // this lane's running sums (N*N / P*P), may be null
+    int learn;                 // 0: the weights were detached from the network's output
+                               // (learn_weight_model = False, :279-282): only g_a_w flows
+
+    template <int N, int P, int K>
+    KV_HD void step(const FilterFwdArgs<R>& f, int t, long tb, R* da, const R* w, const R* wn,
+                    const R* C, const R* mp, R mu, R* a_extra, R* Cb, R* At_bar,
+                    R* mp_extra) const {
+        constexpr int UNIT = P + 1 + K;
+        const long B = f.B;
+        if (g_alpha) {
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) da[k] += g_alpha[(tb + B) * K + k];
+        }
+        R dl[K];
+        {
+            R dot = R(0);
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) dot += da[k] * wn[k];
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) dl[k] = learn ? wn[k] * (da[k] - dot) : R(0);
+        }
+        gstore<R, K>(d_logits + tb * K, dl);
+        R aw[P], awb[P];
+        gload<R, P>(q.a_w + tb * P, aw);
+        gload_or_zero<R, P>(g_a_w, tb * P, awb);
+#pragma GCC unroll 8
+        for (int j = 0; j < q.hidden; ++j) {
+            const R* u = q.net + (long)j * UNIT;
+            R pre = u[P];
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) pre += u[i] * aw[i];
+            R hb = R(0);
+            KV_UNROLL
+            for (int k = 0; k < K; ++k) hb += u[P + 1 + k] * dl[k];
+            hb = pre > R(0) ? hb : R(0);
+            KV_UNROLL
+            for (int i = 0; i < P; ++i) awb[i] += u[i] * hb;
+        }
+        R aib[P];
+        KV_UNROLL
+        for (int i = 0; i < P; ++i) {
+            a_extra[i] = mu * awb[i];
+            aib[i] = (R(1) - mu) * awb[i];
+        }
+        R A[N * N], z[N], zb[N];
+        mix<R, K, N * N>(w, f.A_K, A);
+        gemv<R, N, N, false, 0>(A, mp, z);
+        if (q.eps_z) {
+            R e[N], L[N * N];
+            gload<R, N>(q.eps_z + tb * N, e);
+            gload<R, N * N>(q.L_Q, L);
+            gemv<R, N, N, false, 1>(L, e, z);
+        }
+        outer_add<R, P, N>(R(1), aib, z, Cb);
+        gemv<R, N, P, true, 0>(C, aib, zb);          // C^T d a_imp
+        vzero<R, N * N>(At_bar);
+        outer_add<R, N, N>(R(1), zb, mp, At_bar);
+        gemv<R, N, N, true, 0>(A, zb, mp_extra);     // A^T d z
+        if (q.eps_a && acc_LR) {
+            R e[P];
+            gload<R, P>(q.eps_a + tb * P, e);
+            outer_add<R, P, P>(R(1), aib, e, acc_LR);
+        }
+        if (q.eps_z && acc_LQ) {
+            R e[N];
+            gload<R, N>(q.eps_z + tb * N, e);
+            outer_add<R, N, N>(R(1), zb, e, acc_LQ);
+        }
+    }
+};
+
+// acc: FilterParamGrads<N,P,K>::LEN running sums followed by N*N (d L_Q) and P*P (d L_R)
+template <typename R, int N, int P, int K>
+KV_HD void filter_backward_masked_mlp_sequence(const FilterBwdArgs<R>& g,
+                                               const MlpNetAdjoint<R>& net, int b, R* acc) {
+    R mpb[N], Ppb[N * N];
+    filter_backward_core<R, N, P, K, false, MlpNetAdjoint<R>>(g, b, acc, mpb, Ppb, net);
     gstore<R, N>(g.d_m_in + (long)b * N, mpb);
     gstore<R, N * N>(g.d_P_in + (long)b * N * N, Ppb);
 }

@@ -760,6 +760,140 @@ def masked_filter_mlp(a, mask, packed, hidden, A_K, C_K, Q, R, m_in, P_in, eps_z
     return m, P, mn, Pn, As, Cs, a_w, alpha
 
 
+def _pack_mlp2_tensors(W1, b1, W2, b2):
+    units = torch.cat([W1, b1.unsqueeze(1), W2.t()], dim=1)
+    return torch.cat([units.reshape(-1), b2]).contiguous()
+
+
+class MaskedFilterMLPFunction(torch.autograd.Function):
+    """The masked filter with the two-layer perceptron weight network inside the recursion
+    (kvae/state_space_model.py:219-352 with an observation mask) as ONE autograd node and one
+    launch per direction:
+    (a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R) ->
+    (mean_filt, cov_filt, mean_pred, cov_pred, mat_As, mat_Cs, a_w, alpha (T+1,B,K)).
+    The backward kernel returns the gradient w.r.t. the network's pre-softmax outputs; the
+    gradients of W1, b1, W2, b2 are two small matrix products on the saved a_w."""
+
+    @staticmethod
+    def forward(ctx, a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R,
+                symmetrize, burn_in, learn, first_weights):
+        capi.require_gpu(a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R)
+        a, mask, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R = map(
+            _c, (a, mask, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R))
+        T, B, p = a.shape
+        K, n = A_K.shape[0], A_K.shape[1]
+        hidden = W1.shape[0]
+        packed = _pack_mlp2_tensors(W1.detach(), b1.detach(), W2.detach(), b2.detach())
+        dims = _dims(T, B, n, p, K, a.dtype, symmetrize, burn_in)
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+        As, Cs, a_w = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p)
+        alpha = new(T + 1, B, K)
+        alpha[0] = 0.0
+        alpha[0, :, :first_weights] = 1.0 / first_weights
+        io = capi.fill(capi.FilterFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                       m_in=m_in, P_in=P_in, carry_per_sequence=int(m_in.dim() == 2),
+                       mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs,
+                       status=status_word(a.device))
+        net = capi.fill(capi.MaskedMlp(), hidden=int(hidden), packed=packed, eps_z=eps_z, L_Q=L_Q,
+                        eps_a=eps_a, L_R=L_R, a_w=a_w)
+        capi.check(capi.load().kvae_filter_forward_masked_mlp(
+            C.byref(dims), C.byref(io), C.byref(net), capi.current_stream_ptr()))
+        ctx.save_for_backward(a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q,
+                              eps_a, L_R, packed, m, P, mn, Pn, As, Cs, a_w, alpha)
+        ctx.dims, ctx.learn = dims, bool(learn)
+        ctx.set_materialize_grads(False)
+        return m, P, mn, Pn, As, Cs, a_w, alpha
+
+    @staticmethod
+    def backward(ctx, g_m, g_P, g_mn, g_Pn, g_As, g_Cs, g_aw, g_alpha):
+        (a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in, eps_z, L_Q, eps_a, L_R, packed,
+         m, P, mn, Pn, As, Cs, a_w, alpha) = ctx.saved_tensors
+        g_m, g_P, g_mn, g_Pn, g_As, g_Cs, g_aw, g_alpha = map(
+            _c, (g_m, g_P, g_mn, g_Pn, g_As, g_Cs, g_aw, g_alpha))   # alive past the launch
+        dims = ctx.dims
+        T, B, n, p, K = dims.T, dims.B, dims.n, dims.p, dims.K
+        new = lambda *s: torch.empty(s, dtype=a.dtype, device=a.device)
+        d_a, d_alpha = new(T, B, p), new(T + 1, B, K)
+        d_m_in, d_P_in = new(B, n), new(B, n, n)
+        d_A_K, d_C_K, d_Q, d_R = new(K, n, n), new(K, p, n), new(n, n), new(p, p)
+        d_logits = new(T, B, K)
+        d_L_Q = new(n, n) if L_Q is not None else None
+        d_L_R = new(p, p) if L_R is not None else None
+        io = capi.FilterBwd()
+        capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m_in=m_in,
+                  P_in=P_in, carry_per_sequence=int(m_in.dim() == 2), mean_filt=m, cov_filt=P,
+                  mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs)
+        capi.fill(io, g_mean_filt=g_m, g_cov_filt=g_P, g_mean_pred=g_mn, g_cov_pred=g_Pn,
+                  g_mat_As=g_As, g_mat_Cs=g_Cs, d_a=d_a, d_alpha=d_alpha, d_m_in=d_m_in,
+                  d_P_in=d_P_in, d_A_K=d_A_K, d_C_K=d_C_K, d_Q=d_Q, d_R=d_R)
+        nb = capi.MaskedMlpBwd()
+        capi.fill(nb.fwd, hidden=int(W1.shape[0]), packed=packed, eps_z=eps_z, L_Q=L_Q,
+                  eps_a=eps_a, L_R=L_R, a_w=a_w)
+        capi.fill(nb, g_a_w=g_aw, g_alpha=g_alpha, d_logits=d_logits, d_L_Q=d_L_Q, d_L_R=d_L_R,
+                  learn_weight_model=int(ctx.learn))
+        lib = capi.load()
+        nbytes = int(lib.kvae_filter_backward_masked_mlp_workspace_bytes(C.byref(dims)))
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=a.device)
+        capi.check(lib.kvae_filter_backward_masked_mlp(C.byref(dims), C.byref(io), C.byref(nb),
+                                                       ws.data_ptr(), nbytes,
+                                                       capi.current_stream_ptr()))
+        dW1 = db1 = dW2 = db2 = None
+        if ctx.learn and any(ctx.needs_input_grad[2:6]):
+            # parameters of the network: logits = W2 relu(W1 a_w + b1) + b2 over all (t, b)
+            x = a_w.reshape(T * B, p)
+            dl = d_logits.reshape(T * B, K)
+            pre = torch.addmm(b1, x, W1.t())
+            h = torch.relu(pre)
+            dW2, db2 = dl.t() @ h, dl.sum(0)
+            dpre = (dl @ W2) * (pre > 0).to(a.dtype)
+            dW1, db1 = dpre.t() @ x, dpre.sum(0)
+        if m_in.dim() == 1:
+            d_m_in = d_m_in.sum(0) if ctx.needs_input_grad[10] else None
+            d_P_in = d_P_in.sum(0) if ctx.needs_input_grad[11] else None
+        return (d_a, None, dW1, db1, dW2, db2, d_A_K, d_C_K, d_Q, d_R, d_m_in, d_P_in, None, d_L_Q,
+                None, d_L_R, None, None, None, None)
+
+
+def masked_mlp_grad_supported(hidden, n, p, K, dtype):
+    """Whether masked_filter_mlp_grad has a kernel for these dimensions."""
+    dims2 = embedding_dims(n, p, K, dtype, fused=True)     # the lane-per-sequence shapes
+    return dims2 is not None and masked_mlp_fits(hidden, dims2[1], dims2[2], dtype)
+
+
+def masked_filter_mlp_grad(a, mask, first, last, A_K, C_K, Q, R, m_in, P_in, eps_z=None, L_Q=None,
+                           eps_a=None, L_R=None, symmetrize=True, burn_in=0,
+                           learn_weight_model=True):
+    """The masked filter with the perceptron ``last(relu(first(.)))`` (two torch.nn.Linear)
+    in the recursion, differentiable: see MaskedFilterMLPFunction.  Returns (mean_filt,
+    cov_filt, mean_pred, cov_pred, mat_As, mat_Cs, a_w, alpha (T+1,B,K)), or None when no
+    kernel covers the dimensions."""
+    T, B, p = a.shape
+    K, n = A_K.shape[0], A_K.shape[1]
+    hidden = first.out_features
+    dims2 = embedding_dims(n, p, K, a.dtype, fused=True)     # the lane-per-sequence shapes
+    if dims2 is None or not masked_mlp_fits(hidden, dims2[1], dims2[2], a.dtype):
+        return None
+    W1, b1, W2, b2 = first.weight, first.bias, last.weight, last.bias
+    if a.dtype != W1.dtype:
+        W1, b1, W2, b2 = (t.to(a.dtype) for t in (W1, b1, W2, b2))
+    flags = (bool(symmetrize), int(burn_in), bool(learn_weight_model), K)
+    if dims2 == (n, p, K):
+        return MaskedFilterMLPFunction.apply(a, mask, W1, b1, W2, b2, A_K, C_K, Q, R, m_in, P_in,
+                                             eps_z, L_Q, eps_a, L_R, *flags)
+    e = _Embedding(n, p, K, *dims2)
+    pad = torch.nn.functional.pad
+    W1p = pad(W1, (0, e.dp))                      # zero columns for the extra inputs
+    W2p = pad(W2, (0, 0, 0, e.dK))                # extra outputs ...
+    b2p = torch.cat([b2, b2.new_full((e.dK,), -1e30)])   # ... whose softmax weight is zero
+    m, P, mn, Pn, As, Cs, a_w, alpha = MaskedFilterMLPFunction.apply(
+        e.vec_p(a), mask, W1p, b1, W2p, b2p, e.bases_A(A_K), e.bases_C(C_K), e.cov_n(Q),
+        e.cov_p(R), e.vec_n(m_in), e.cov_n(P_in), e.vec_n(eps_z), e.cov_n(L_Q), e.vec_p(eps_a),
+        e.cov_p(L_R), *flags)
+    return (e.cut_n(m), e.cut_nn(P), e.cut_n(mn), e.cut_nn(Pn), e.cut_nn(As), e.cut_pn(Cs),
+            e.cut_p(a_w), e.cut_K(alpha))
+
+
 FILTER_SMOOTH_OUTPUTS = ("mean_filt", "cov_filt", "mean_pred", "cov_pred", "mat_As", "mat_Cs",
                          "a_w", "alpha", "mean_smooth", "cov_smooth", "zs", "as_resampled")
 

@@ -275,6 +275,19 @@ class StateSpaceModel(nn.Module):
         w = torch.full((B, self.K), 1.0 / self.K, dtype=as_.dtype, device=as_.device)
         m_pred = self.initial_state_mean.expand(B, -1).contiguous()
         P_pred = self.initial_state_covariance.expand(B, -1, -1).contiguous()
+        layers = getattr(self.weight_model, "layers", None)
+        if (torch.is_grad_enabled() and as_.is_cuda and self.in_kernel_weight_network
+                and layers is not None and len(layers) == 2
+                and F.masked_mlp_grad_supported(layers[0].out_features, self.z_dim, self.a_dim,
+                                                self.K, as_.dtype)):
+            # two-layer perceptron under autograd: one launch per direction
+            out = F.masked_filter_mlp_grad(
+                as_, mask, layers[0], layers[1], A_K, C_K, Q, R, self.initial_state_mean,
+                self.initial_state_covariance, *self._filter_draws_split(as_, state_noise,
+                                                                          obs_noise, L_Q, L_R),
+                symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
+            if out is not None:
+                return out[:7] + (out[7][:T],)
         if (not torch.is_grad_enabled() and as_.is_cuda
                 and F.impute_supported(self.z_dim, self.a_dim, self.K, as_.dtype, as_.device)):
             layers = getattr(self.weight_model, "layers", None)
@@ -381,6 +394,11 @@ class StateSpaceModel(nn.Module):
             if obs_noise:
                 ea.append(self._draw((B, self.a_dim), as_))
         return (torch.stack(ez) if state_noise else None, torch.stack(ea) if obs_noise else None)
+
+    def _filter_draws_split(self, as_, state_noise, obs_noise, L_Q, L_R):
+        """(eps_z, L_Q, eps_a, L_R) in the argument order of the masked-filter kernels."""
+        eps_z, eps_a = self._filter_draws(as_, state_noise, obs_noise)
+        return eps_z, L_Q, eps_a, L_R
 
     def _smoother_draws(self, as_, state_noise, obs_noise):
         """(eps_state (T,B,n), eps_obs (T,B,p)) of the smoother's samples; None where the

@@ -80,6 +80,37 @@ int masked_mlp_fwd(const kvae_dims* d, const kvae_filter_fwd* io, const kvae_mas
     for (int b = 0; b < d->B; ++b) filter_forward_masked_mlp_sequence<R, N, P, K>(g, q, b);
     return 0;
 }
+template <typename R, int N, int P, int K>
+int masked_mlp_bwd(const kvae_dims* d, const kvae_filter_bwd* io, const kvae_masked_mlp_bwd* nb) {
+    using PG = FilterParamGrads<N, P, K>;
+    constexpr int LEN = PG::LEN + N * N + P * P;
+    FilterBwdArgs<R> g;
+    g.f = mk<R>(d, &io->fwd);
+    g.burn_in = d->burn_in;
+    g.g_m = (const R*)io->g_mean_filt; g.g_P = (const R*)io->g_cov_filt;
+    g.g_mn = (const R*)io->g_mean_pred; g.g_Pn = (const R*)io->g_cov_pred;
+    g.g_As = (const R*)io->g_mat_As; g.g_Cs = (const R*)io->g_mat_Cs;
+    g.d_a = (R*)io->d_a; g.d_alpha = (R*)io->d_alpha;
+    g.d_m_in = (R*)io->d_m_in; g.d_P_in = (R*)io->d_P_in; g.partial = nullptr;
+    g.bar_As = nullptr; g.bar_Cs = nullptr;
+    std::vector<R> acc(LEN, R(0));
+    MlpNetAdjoint<R> net;
+    net.q = MaskedNetArgs<R>{nb->fwd.hidden,        (const R*)nb->fwd.packed, (const R*)nb->fwd.eps_z,
+                             (const R*)nb->fwd.L_Q, (const R*)nb->fwd.eps_a,  (const R*)nb->fwd.L_R,
+                             (R*)nb->fwd.a_w,       nullptr};
+    net.g_a_w = (const R*)nb->g_a_w; net.g_alpha = (const R*)nb->g_alpha;
+    net.d_logits = (R*)nb->d_logits; net.learn = nb->learn_weight_model;
+    net.acc_LQ = acc.data() + PG::LEN; net.acc_LR = acc.data() + PG::LEN + N * N;
+    for (int b = 0; b < d->B; ++b)
+        filter_backward_masked_mlp_sequence<R, N, P, K>(g, net, b, acc.data());
+    put<R>(io->d_A_K, acc.data() + PG::OFF_A, K * N * N);
+    put<R>(io->d_C_K, acc.data() + PG::OFF_C, K * P * N);
+    put<R>(io->d_Q, acc.data() + PG::OFF_Q, N * N);
+    put<R>(io->d_R, acc.data() + PG::OFF_R, P * P);
+    put<R>(nb->d_L_Q, acc.data() + PG::LEN, N * N);
+    put<R>(nb->d_L_R, acc.data() + PG::LEN + N * N, P * P);
+    return 0;
+}
 // every output present (the caller allocates all of them): checks the fused statements
 template <typename R, int N, int P, int K>
 int filter_smooth(const kvae_dims* d, const kvae_filter_fwd* f, const kvae_masked_mlp* net,
@@ -364,6 +395,17 @@ int hostsim_filter_forward_masked_mlp(const kvae_dims* d, const kvae_filter_fwd*
 #define FN masked_mlp_fwd
 #undef ARGS
 #define ARGS (d, io, net)
+    DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+#undef ARGS
+#define ARGS (d, io)
+}
+int hostsim_filter_backward_masked_mlp(const kvae_dims* d, const kvae_filter_bwd* io,
+                                       const kvae_masked_mlp_bwd* nb) {
+#define FN masked_mlp_bwd
+#undef ARGS
+#define ARGS (d, io, nb)
     DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN

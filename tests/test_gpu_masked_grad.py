@@ -1,0 +1,117 @@
+"""The masked filter with the perceptron weight network in the recursion, under autograd
+(functions.masked_filter_mlp_grad -> kvae_filter_forward_masked_mlp /
+kvae_filter_backward_masked_mlp) against autograd through the float64 oracle's masked
+filter (oracle/kalman_oracle.py, pinned to the reference by the golden fixtures) with the
+same perceptron: all eight outputs and the gradients of a random linear functional of them
+w.r.t. observations, bases, noise covariances, initial state and the network's parameters.
+Tolerances (max-norm relative): float64 1e-8, float32 1e-4."""
+import pytest
+import torch
+
+from golden_util import rel_err
+from oracle import kalman_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["filter_means", "filter_covariances", "filter_next_means", "filter_next_covariances",
+         "mat_As", "mat_Cs", "as_for_weight", "weights"]
+
+
+def run_case(n, p, K, dtype, sample, burn_in, learn, T=9, B=70, H=16, seed=0):
+    from kalman_vae_amd import functions as F
+    torch.manual_seed(seed + n * 13 + p)
+    dev = torch.device("cuda:0")
+    first, last = torch.nn.Linear(p, H).to(dtype), torch.nn.Linear(H, K).to(dtype)
+    A_K = (torch.eye(n) + 0.15 * torch.randn(K, n, n)).to(dtype)
+    C_K = (0.5 * torch.randn(K, p, n)).to(dtype)
+    Lq = 0.4 * torch.eye(n) + 0.05 * torch.randn(n, n)
+    Lr = 0.4 * torch.eye(p) + 0.05 * torch.randn(p, p)
+    Q, R = (Lq @ Lq.T + 0.01 * torch.eye(n)).to(dtype), (Lr @ Lr.T + 0.01 * torch.eye(p)).to(dtype)
+    Q, R = 0.5 * (Q + Q.T), 0.5 * (R + R.T)
+    m0, P0 = (0.3 * torch.randn(n)).to(dtype), (1.5 * torch.eye(n)).to(dtype)
+    a = torch.randn(T, B, p).to(dtype)
+    mask = (torch.rand(T, B) < 0.6).to(dtype)
+    mask[0] = 1.0
+    eps_z = torch.randn(T, B, n).to(dtype) if sample else None
+    eps_a = torch.randn(T, B, p).to(dtype) if sample else None
+
+    # oracle in float64 on the same (rounded) values
+    f64 = lambda t: None if t is None else t.double()
+    f1 = torch.nn.Linear(p, H).double()
+    l1 = torch.nn.Linear(H, K).double()
+    f1.load_state_dict({k: v.double() for k, v in first.state_dict().items()})
+    l1.load_state_dict({k: v.double() for k, v in last.state_dict().items()})
+    leaves = [f64(t).requires_grad_(True) for t in (a, A_K, C_K, Q, R, m0, P0)]
+    net = lambda x: torch.softmax(l1(torch.relu(f1(x))), dim=-1)
+    want = O.kalman_filter(*leaves, net, mask=f64(mask), eps_state=f64(eps_z), eps_obs=f64(eps_a),
+                           learn_weight_model=learn, burn_in=burn_in)
+    cot = {k: torch.randn_like(want[k]) for k in NAMES}
+    loss = sum((cot[k] * want[k]).sum() for k in NAMES)
+    params = leaves + [f1.weight, f1.bias, l1.weight, l1.bias]
+    gref = torch.autograd.grad(loss, params, allow_unused=True)
+
+    d = lambda t: None if t is None else t.to(dev)
+    first, last = first.to(dev), last.to(dev)
+    gl = [d(t).requires_grad_(True) for t in (a, A_K, C_K, Q, R, m0, P0)]
+    L_Q = F.cholesky_factor(gl[3]) if sample else None
+    L_R = F.cholesky_factor(gl[4]) if sample else None
+    out = F.masked_filter_mlp_grad(gl[0], d(mask), first, last, gl[1], gl[2], gl[3], gl[4], gl[5],
+                                   gl[6], d(eps_z), L_Q, d(eps_a), L_R, burn_in=burn_in,
+                                   learn_weight_model=learn)
+    assert out is not None
+    got = dict(zip(NAMES, out))
+    got["weights"] = got["weights"][:T]
+    tol = 1e-8 if dtype == torch.float64 else 1e-4
+    bad = []
+    for k in NAMES:
+        e = rel_err(got[k], want[k])
+        if not e < tol:
+            bad.append(f"{k}: {e:.2e}")
+    loss_g = sum((d(cot[k]).to(dtype) * got[k]).sum() for k in NAMES)
+    gp = gl + [first.weight, first.bias, last.weight, last.bias]
+    ggot = torch.autograd.grad(loss_g, gp, allow_unused=True)
+    pn = ["a", "A_K", "C_K", "Q", "R", "m0", "P0", "W1", "b1", "W2", "b2"]
+    for name, g, r in zip(pn, ggot, gref):
+        if r is None:
+            assert g is None or float(g.abs().max()) == 0.0, name
+            continue
+        assert g is not None, name
+        e = rel_err(g, r)
+        if not e < tol:
+            bad.append(f"grad {name}: {e:.2e}")
+    assert F.read_status(dev) == 0
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.parametrize("sample,burn_in,learn", [(False, 0, True), (True, 2, True),
+                                                  (True, 0, False)])
+@pytest.mark.parametrize("n,p,K,dtype", [(4, 2, 3, torch.float64), (4, 2, 3, torch.float32),
+                                         (8, 4, 4, torch.float64), (2, 1, 2, torch.float64),
+                                         (5, 3, 4, torch.float64), (4, 2, 5, torch.float32)])
+def test_masked_perceptron_filter_matches_oracle_autograd(n, p, K, dtype, sample, burn_in, learn):
+    run_case(n, p, K, dtype, sample, burn_in, learn)
+
+
+def test_module_masked_training_step_uses_one_launch_per_direction(monkeypatch):
+    """StateSpaceModel.kalman_filter with a mask and the perceptron network under autograd
+    goes through the single-node path (not T one-step launches)."""
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    from kalman_vae_amd import functions as F
+    calls = []
+    real = F.masked_filter_mlp_grad
+    monkeypatch.setattr(F, "masked_filter_mlp_grad",
+                        lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    steps = []
+    real_steps = F.kalman_filter_steps
+    monkeypatch.setattr(F, "kalman_filter_steps",
+                        lambda *a, **k: (steps.append(1), real_steps(*a, **k))[1])
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ssm = StateSpaceModel(2, 4, 3, "mlp", hidden_dim=16).to(dev).train()
+    a = torch.randn(10, 33, 2, device=dev, requires_grad=True)
+    mask = (torch.rand(10, 33, device=dev) < 0.7).float()
+    out = ssm.kalman_filter(a, SampleControl(), observation_mask=mask)
+    (out[0].sum() + out[6].sum()).backward()
+    assert calls == [1] and steps == []
+    assert a.grad is not None and torch.isfinite(a.grad).all()
+    assert all(p.grad is not None for p in ssm.weight_model.parameters())

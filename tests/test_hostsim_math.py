@@ -282,3 +282,104 @@ def test_fused_filter_smoother_statements_equal_separate_calls(n, p, K):
         assert torch.equal(out_f[k], f[k]), k
     for k in names_s:
         assert torch.equal(out_s[k], s[k]), k
+
+
+@pytest.mark.parametrize("n,p,K", [(4, 2, 3), (3, 2, 2)])
+@pytest.mark.parametrize("sample,burn_in,learn", [(False, 0, True), (True, 2, True),
+                                                  (True, 0, False)])
+def test_masked_filter_with_network_adjoint(n, p, K, sample, burn_in, learn):
+    """filter_backward_masked_mlp_sequence (the source of kvae_filter_backward_masked_mlp)
+    against autograd through the oracle's masked filter with the same perceptron: random
+    cotangents on all eight outputs, gradients w.r.t. observations, bases, noise
+    covariances (through the imputation's Cholesky factors too), initial state and the four
+    parameter tensors of the network.  float64, 1e-9."""
+    import ctypes as C
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd.functions import pack_mlp2
+    from kernel_harness import hostsim_lib
+    from oracle import kalman_oracle as O
+    torch.manual_seed(n * 11 + p + burn_in)
+    T, B, H, dt = 6, 4, 7, torch.float64
+    first, last = torch.nn.Linear(p, H).to(dt), torch.nn.Linear(H, K).to(dt)
+    leaf = lambda t: t.to(dt).requires_grad_(True)
+    A_K = leaf(torch.eye(n) + 0.2 * torch.randn(K, n, n))
+    C_K = leaf(0.5 * torch.randn(K, p, n))
+    Lq = 0.3 * torch.eye(n) + 0.05 * torch.randn(n, n)
+    Lr = 0.3 * torch.eye(p) + 0.05 * torch.randn(p, p)
+    Q, R = leaf(Lq @ Lq.T + 0.01 * torch.eye(n)), leaf(Lr @ Lr.T + 0.01 * torch.eye(p))
+    m0, P0 = leaf(torch.randn(n)), leaf(2.0 * torch.eye(n) + 0.1 * torch.ones(n, n))
+    a = leaf(torch.randn(T, B, p))
+    mask = torch.rand(T, B).to(dt)          # fractional: the blend is arithmetic
+    mask[0] = 1.0
+    eps_z = torch.randn(T, B, n).to(dt) if sample else None
+    eps_a = torch.randn(T, B, p).to(dt) if sample else None
+    net = lambda x: torch.softmax(last(torch.relu(first(x))), dim=-1)
+    want = O.kalman_filter(a, A_K, C_K, Q, R, m0, P0, net, mask=mask, eps_state=eps_z,
+                           eps_obs=eps_a, learn_weight_model=learn, burn_in=burn_in)
+    names = ["filter_means", "filter_covariances", "filter_next_means", "filter_next_covariances",
+             "mat_As", "mat_Cs", "as_for_weight", "weights"]
+    cot = {k: torch.randn_like(want[k]) for k in names}
+    loss = sum((cot[k] * want[k]).sum() for k in names)
+    params = [a, A_K, C_K, Q, R, m0, P0, first.weight, first.bias, last.weight, last.bias]
+    gref = torch.autograd.grad(loss, params, allow_unused=True)
+
+    # forward through the host build, then its adjoint
+    new = lambda *s: torch.zeros(s, dtype=dt)
+    c = lambda t: t.detach().contiguous()
+    m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+    As, Cs, a_w, alpha = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p), new(T + 1, B, K)
+    alpha[0] = 1.0 / K
+    status = torch.zeros(1, dtype=torch.int32)
+    L_Q = torch.linalg.cholesky(c(Q)).contiguous().requires_grad_(True) if sample else None
+    L_R = torch.linalg.cholesky(c(R)).contiguous().requires_grad_(True) if sample else None
+    packed = pack_mlp2(first, last)
+    keep = [c(t) for t in (a, A_K, C_K, Q, R, m0, P0)]
+    dims = capi.Dims(T, B, n, p, K, capi.KVAE_F64, 1, burn_in)
+    fio = capi.fill(capi.FilterFwd(), a=keep[0], alpha=alpha, mask=mask, A_K=keep[1], C_K=keep[2],
+                    Q=keep[3], R=keep[4], m_in=keep[5], P_in=keep[6], carry_per_sequence=0,
+                    mean_filt=m, cov_filt=P, mean_pred=mn, cov_pred=Pn, mat_As=As, mat_Cs=Cs,
+                    status=status)
+    lq, lr = (c(L_Q) if sample else None), (c(L_R) if sample else None)
+    q = capi.fill(capi.MaskedMlp(), hidden=H, packed=packed, eps_z=eps_z, L_Q=lq, eps_a=eps_a,
+                  L_R=lr, a_w=a_w)
+    lib = hostsim_lib()
+    fwd = lib.hostsim_filter_forward_masked_mlp
+    fwd.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.FilterFwd), C.POINTER(capi.MaskedMlp)]
+    assert fwd(C.byref(dims), C.byref(fio), C.byref(q)) == 0
+    g_alpha = torch.cat([cot["weights"], new(1, B, K)]).contiguous()
+    out = dict(d_a=new(T, B, p), d_alpha=new(T + 1, B, K), d_m_in=new(B, n), d_P_in=new(B, n, n),
+               d_A_K=new(K, n, n), d_C_K=new(K, p, n), d_Q=new(n, n), d_R=new(p, p))
+    bio = capi.FilterBwd()
+    bio.fwd = fio
+    capi.fill(bio, g_mean_filt=cot["filter_means"], g_cov_filt=cot["filter_covariances"],
+              g_mean_pred=cot["filter_next_means"], g_cov_pred=cot["filter_next_covariances"],
+              g_mat_As=cot["mat_As"], g_mat_Cs=cot["mat_Cs"], **out)
+    d_logits, d_LQ, d_LR = new(T, B, K), new(n, n), new(p, p)
+    nb = capi.MaskedMlpBwd()
+    nb.fwd = q
+    capi.fill(nb, g_a_w=cot["as_for_weight"], g_alpha=g_alpha, d_logits=d_logits,
+              d_L_Q=d_LQ if sample else None, d_L_R=d_LR if sample else None,
+              learn_weight_model=int(learn))
+    bwd = lib.hostsim_filter_backward_masked_mlp
+    bwd.argtypes = [C.POINTER(capi.Dims), C.POINTER(capi.FilterBwd), C.POINTER(capi.MaskedMlpBwd)]
+    assert bwd(C.byref(dims), C.byref(bio), C.byref(nb)) == 0
+    got = {"a": out["d_a"], "A_K": out["d_A_K"], "C_K": out["d_C_K"], "Q": out["d_Q"].clone(),
+           "R": out["d_R"].clone(), "m0": out["d_m_in"].sum(0), "P0": out["d_P_in"].sum(0)}
+    if sample:   # the imputation's factors are functions of Q and R
+        got["Q"] += torch.autograd.grad(L_Q_of(Q), Q, d_LQ)[0]
+        got["R"] += torch.autograd.grad(L_Q_of(R), R, d_LR)[0]
+    # the network's parameters from d_logits, as the autograd node does
+    x, dl = a_w.reshape(T * B, p), d_logits.reshape(T * B, K)
+    pre = x @ first.weight.detach().T + first.bias.detach()
+    dpre = (dl @ last.weight.detach()) * (pre > 0).to(dt)
+    got.update(W1=dpre.T @ x, b1=dpre.sum(0), W2=dl.T @ torch.relu(pre), b2=dl.sum(0))
+    for (name, val), ref in zip(got.items(), gref):
+        if ref is None:
+            assert float(val.abs().max()) == 0.0, name
+            continue
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((val - ref).abs().max()) / scale < 1e-9, (name, float((val - ref).abs().max()) / scale)
+
+
+def L_Q_of(M):
+    return torch.linalg.cholesky(M)
