@@ -153,11 +153,18 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         load_gx(t + 1 < T ? t + 1 : t, gx);
         float2 res[4][6];
         auto activate = [&](int i, int hf) {
+#ifdef KVAE_EXP_NOACT
+            const float a_i = acc[0][hf][i], a_f = acc[1][hf][i], a_g = acc[2][hf][i], a_o = acc[3][hf][i];
+            const float cn = a_f * cst[i][hf] + a_i * a_g;
+            cst[i][hf] = cn;
+            const float hn = a_o * cn * 1e-3f;
+#else
             const float a_i = sigmoidf_(acc[0][hf][i]), a_f = sigmoidf_(acc[1][hf][i]);
             const float a_g = tanhf_(acc[2][hf][i]), a_o = sigmoidf_(acc[3][hf][i]);
             const float cn = a_f * cst[i][hf] + a_i * a_g;
             cst[i][hf] = cn;
             const float hn = a_o * tanhf_(cn);
+#endif
             if (hf == 0) {
                 res[i][0].x = a_i; res[i][1].x = a_f; res[i][2].x = a_g; res[i][3].x = a_o;
                 res[i][4].x = hn; res[i][5].x = cn;
@@ -198,6 +205,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         for (int i = 0; i < 4; ++i) {
             const int lr = 4 * s + i, row = r0 + lr;
             *reinterpret_cast<float2*>(h_tile + lr * RLDA + ub) = res[i][4];
+#ifndef KVAE_EXP_NOSTORE
             if (FULL || row < B) {
                 const long o = (long)row * RH + ub;
                 store_streaming(h + t * BH + o, res[i][4]);
@@ -210,10 +218,13 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
                     store_streaming(gr + 3 * RH, res[i][3]);
                 }
             }
+#endif
         }
         // orders this step's h writes before the next step's reads; the buffer written in
         // step t+1 was last read in step t, before this barrier
+#ifndef KVAE_EXP_NOBARRIER
         lds_barrier();
+#endif
     }
 }
 
