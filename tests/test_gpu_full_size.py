@@ -194,4 +194,12 @@ def test_config3_masked_imputation_shard_subset(net, monkeypatch):
     # where nothing was missing the imputed sequence is the observed one
     seen = mask.bool().unsqueeze(-1).expand_as(a)
     assert torch.equal(filter_as[seen], a[seen])
+    # the imputation consumer's call (one launch with the perceptron network, the two calls
+    # otherwise) against the same oracle subset
+    imp_as, imp_res = ssm.impute(a, sc, observation_mask=mask)
+    for k, v, want in (("impute.filter_as", imp_as, f["as_for_weight"]),
+                       ("impute.as_resampled", imp_res, s["as_resampled"])):
+        e = rel_err(v[:, idx], want)
+        if not e < TOL:
+            failures.append(f"{k}: {e:.2e}")
     assert not failures, "; ".join(failures)
