@@ -294,7 +294,7 @@ int kvae_impute_observation(const kvae_dims *d, const void *w, const void *A_K, 
  * (the weights of the first step, uniform in the reference) and rows 1..T are WRITTEN
  * (the caller owns the buffer; the const in the struct is not honoured here), and
  * io->mask NULL means nothing is masked.  Forward only (inference).  Small state
- * dimensions, hidden * (p + 1 + K) + K elements must fit 16 KB.                     */
+ * dimensions, hidden * (p + 1 + K) + K elements must fit 64 KB.                     */
 typedef struct kvae_masked_mlp {
     int32_t hidden, _pad;
     const void *packed; /* hidden rows of [W1[j,0..p-1], b1[j], W2[0..K-1,j]], then b2 (K) */
@@ -318,7 +318,7 @@ int kvae_filter_forward_masked_mlp(const kvae_dims *d, const kvae_filter_fwd *io
  *   advance: A = sum_k w_k A_K[k], C likewise (:545-548); mean_pred <- A mean_pred (:549);
  *            cov_pred <- sym(Q) when `sample`, else sym(A cov_pred A^T + Q) (:550-563)
  * phase KVAE_ROLLOUT_ALL: all S steps in one launch with the two-layer perceptron
- *   `packed_mlp` (layout of kvae_masked_mlp.packed, `hidden` units, must fit 16 KB)
+ *   `packed_mlp` (layout of kvae_masked_mlp.packed, `hidden` units, must fit 64 KB)
  *   evaluated in the loop.
  * phase KVAE_ROLLOUT_EMIT / KVAE_ROLLOUT_ADVANCE (S must be 1): the two halves of one step
  *   for a caller that runs a recurrent weight network in between; ADVANCE reads the

@@ -9,7 +9,7 @@
 namespace kvae {
 
 constexpr int FS_BLOCK = 64;   // one wavefront per workgroup
-constexpr int FS_NET_MAX_BYTES = 16 * 1024;
+constexpr int FS_NET_MAX_BYTES = 64 * 1024;
 
 template <typename R, int N, int P, int K, bool NET>
 __global__ void __launch_bounds__(FS_BLOCK)

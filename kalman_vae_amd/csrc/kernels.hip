@@ -337,7 +337,7 @@ int run_impute(const ImputeArgs<R>& g, hipStream_t s) {
 // per time step.  Every lane reads the same entry of the packed network (a few KB) at the
 // same time: `net` is a read-only, non-aliased kernel argument so that those loads are
 // scalar loads (one per wavefront, served by the scalar cache) feeding SGPR operands.
-constexpr int MASKED_NET_MAX_BYTES = 16 * 1024;
+constexpr int MASKED_NET_MAX_BYTES = 64 * 1024;   // read through the scalar cache; not staged
 
 template <typename R, int N, int P, int K>
 __global__ void __launch_bounds__(SEQ_BLOCK)

@@ -10,7 +10,7 @@
 namespace kvae {
 
 constexpr int MB_BLOCK = 64;   // one wavefront per workgroup
-constexpr int MB_NET_MAX_BYTES = 16 * 1024;
+constexpr int MB_NET_MAX_BYTES = 64 * 1024;
 
 template <typename R, int N, int P, int K>
 struct MaskedParamGrads {

@@ -1,25 +1,21 @@
 // kvae_predict_future: the open-loop rollout of kalman_rollout.h, one lane per sequence.
 // With a two-layer perceptron weight network all new steps are ONE launch (the packed
-// network is staged in LDS and read by broadcast); with a recurrent network the caller
+// network is read with scalar loads); with a recurrent network the caller
 // runs the network between a one-step EMIT launch and a one-step ADVANCE launch.
 #include "launch_common.h"
 #include "kalman_rollout.h"
 
 namespace kvae {
 
-constexpr int ROLLOUT_NET_LDS_BYTES = 16 * 1024;
+constexpr int ROLLOUT_NET_MAX_BYTES = 64 * 1024;
 constexpr int SEQ_BLOCK = 64;   // one wavefront per workgroup, one lane per sequence
 inline unsigned seq_blocks(long B) { return (unsigned)((B + SEQ_BLOCK - 1) / SEQ_BLOCK); }
 
 template <typename R, int N, int P, int K>
-__global__ void __launch_bounds__(SEQ_BLOCK) rollout_kernel(RolloutArgs<R> g) {
-    __shared__ __attribute__((aligned(16))) R net[ROLLOUT_NET_LDS_BYTES / sizeof(R)];
-    if (g.phase == ROLLOUT_ALL) {
-        const int len = g.hidden * (P + 1 + K) + K;
-        for (int e = threadIdx.x; e < len; e += SEQ_BLOCK) net[e] = g.net[e];
-        __syncthreads();
-        g.net = net;
-    }
+__global__ void __launch_bounds__(SEQ_BLOCK)
+rollout_kernel(RolloutArgs<R> g, const R* __restrict__ net) {
+    // read-only, non-aliased: the (uniform) loads of the network are scalar loads
+    g.net = net;
     const long b = (long)blockIdx.x * SEQ_BLOCK + threadIdx.x;
     if (b < g.B) rollout_sequence<R, N, P, K>(g, (int)b);
 }
@@ -27,19 +23,19 @@ __global__ void __launch_bounds__(SEQ_BLOCK) rollout_kernel(RolloutArgs<R> g) {
 template <typename R, int N, int P, int K>
 int run_rollout(const kvae_dims* d, const kvae_rollout* io, hipStream_t s) {
     if (io->phase == ROLLOUT_ALL &&
-        (size_t)(io->hidden * (P + 1 + K) + K) * sizeof(R) > (size_t)ROLLOUT_NET_LDS_BYTES)
+        (size_t)(io->hidden * (P + 1 + K) + K) * sizeof(R) > (size_t)ROLLOUT_NET_MAX_BYTES)
         return KVAE_E_UNSUPPORTED;
     RolloutArgs<R> g;
     g.S = d->T; g.B = d->B; g.hidden = io->hidden; g.phase = io->phase; g.sample = io->sample;
     g.A_K = (const R*)io->A_K; g.C_K = (const R*)io->C_K; g.Q = (const R*)io->Q;
     g.mn_in = (const R*)io->mean_pred; g.Pn_in = (const R*)io->cov_pred;
-    g.C_in = (const R*)io->mat_C; g.eps = (const R*)io->eps; g.net = (const R*)io->packed_mlp;
+    g.C_in = (const R*)io->mat_C; g.eps = (const R*)io->eps; g.net = nullptr;
     g.alpha = (const R*)io->alpha;
     g.as_new = (R*)io->as_new; g.means = (R*)io->means; g.covs = (R*)io->covs;
     g.mn_new = (R*)io->mean_pred_new; g.Pn_new = (R*)io->cov_pred_new;
     g.As_new = (R*)io->mat_As_new; g.Cs_new = (R*)io->mat_Cs_new; g.status = io->status;
     hipLaunchKernelGGL((rollout_kernel<R, N, P, K>), dim3((unsigned)seq_blocks(d->B)),
-                       dim3(SEQ_BLOCK), 0, s, g);
+                       dim3(SEQ_BLOCK), 0, s, g, (const R*)io->packed_mlp);
     return launch_status();
 }
 

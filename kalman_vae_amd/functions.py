@@ -702,8 +702,8 @@ def _pad_packed_mlp(e, packed, hidden):
 
 
 def masked_mlp_fits(hidden, p, K, dtype):
-    """Whether the packed two-layer network fits the 16 KB the kernel stages it in."""
-    return (hidden * (p + 1 + K) + K) * torch.empty((), dtype=dtype).element_size() <= 16 * 1024
+    """Whether the packed two-layer network is within the 64 KB the kernels accept."""
+    return (hidden * (p + 1 + K) + K) * torch.empty((), dtype=dtype).element_size() <= 64 * 1024
 
 
 @torch.no_grad()

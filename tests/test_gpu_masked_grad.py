@@ -22,7 +22,7 @@ def run_case(n, p, K, dtype, sample, burn_in, learn, T=9, B=70, H=16, seed=0):
     torch.manual_seed(seed + n * 13 + p)
     dev = torch.device("cuda:0")
     first, last = torch.nn.Linear(p, H).to(dtype), torch.nn.Linear(H, K).to(dtype)
-    A_K = (torch.eye(n) + 0.15 * torch.randn(K, n, n)).to(dtype)
+    A_K = (0.9 * torch.eye(n) + 0.3 / n * torch.randn(K, n, n)).to(dtype)    # stable over long T
     C_K = (0.5 * torch.randn(K, p, n)).to(dtype)
     Lq = 0.4 * torch.eye(n) + 0.05 * torch.randn(n, n)
     Lr = 0.4 * torch.eye(p) + 0.05 * torch.randn(p, p)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP library against the float64 oracle: random T, B,
-dimensions, masks, options, both small-state families and both large-state families, and the\none-launch masked filter with the perceptron network inside.
-Uses the same checks as tests/test_gpu_kernels.py.  usage: stress_parity.py [cases] [seed]"""
+dimensions, masks, options, both small-state families and both large-state families, the
+one-launch masked filter with the perceptron network inside (forward, and under autograd),
+the fused objective and the one-launch filter + smoother.
+Uses the same checks as the GPU tests.  usage: stress_parity.py [cases] [seed]"""
 import os
 import random
 import sys
@@ -13,11 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import kernel_checks as KC  # noqa: E402
+import test_gpu_fused_inference as TFI  # noqa: E402
+import test_gpu_masked_grad as TMG  # noqa: E402
 from kernel_harness import Backend  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SMALL = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4)]
+SMALL = [(4, 2, 3), (2, 1, 2), (3, 2, 2), (8, 4, 4), (4, 2, 8)]
+ODD = [(5, 3, 4), (4, 2, 5), (3, 1, 1), (7, 4, 2), (2, 2, 3)]     # run as a block of a larger problem
 LARGE = [(32, 16, 8), (16, 8, 4)]
 self_check = bool(os.environ.get("STRESS_SELF_CHECK"))
 if self_check:                               # the sweep must notice errors: impossible tolerance
@@ -34,7 +39,8 @@ for i in range(cases):
     os.environ["KVAE_LARGE_STATE"] = rng.choice(["tile", "lds"])
     sym, burn = rng.random() < 0.7, rng.choice([0, 0, 1, 3])
     burn = min(burn, max(T - 1, 0))
-    kind = rng.choice(["filter", "smooth", "elbo"] + ([] if large else ["masked_mlp"]))
+    kind = rng.choice(["filter", "smooth", "elbo"]
+                      + ([] if large else ["masked_mlp", "loss", "masked_grad", "fused_inference"]))
     desc = (f"{kind} T={T} B={B} n={n} p={p} K={K} {str(dtype)[6:]} lanes={os.environ['KVAE_SEQ_LANES']} "
             f"large={os.environ['KVAE_LARGE_STATE']} sym={sym} burn_in={burn}")
     try:
@@ -47,6 +53,36 @@ for i in range(cases):
                                 hidden=rng.choice([1, 7, 32, 128, 200]), dtype=dtype, seed=4000 + i,
                                 mask_kind=rng.choice(["none", "binary", "fractional"]),
                                 sample=rng.random() < 0.5, symmetrize=sym)
+        elif kind == "loss":
+            KC.check_loss(be, T=max(T, 2), B=B, n=n, p=p, K=K, dtype=dtype, seed=5000 + i,
+                          mask_kind=rng.choice(["none", "binary"]), symmetrize=sym, burn_in=burn)
+        elif kind == "masked_grad":
+            no, po, Ko = rng.choice(SMALL + ODD)
+            TMG.run_case(no, po, Ko, dtype, sample=rng.random() < 0.5, burn_in=burn,
+                         learn=rng.random() < 0.8, T=max(T, 2), B=B, H=rng.choice([1, 7, 32, 128]),
+                         seed=6000 + i)
+            desc += f" (dims {no},{po},{Ko})"
+        elif kind == "fused_inference":
+            no, po, Ko = rng.choice(SMALL + ODD)
+            from kalman_vae_amd import functions as F
+            d = TFI.problem(max(T, 2), B, no, po, Ko, dtype, 7000 + i, rng.random() < 0.5)
+            sample = d["eps_state"] is not None
+            alpha = torch.softmax(torch.randn(max(T, 2) + 1, B, Ko, dtype=dtype, device="cuda:0"), -1)
+            with torch.no_grad():
+                filt = F.kalman_filter_steps(d["a"], alpha, d["mask"], d["A_K"], d["C_K"], d["Q"],
+                                             d["R"], d["m0"], d["P0"], symmetrize=sym)
+                smo = F.kalman_smooth_steps(*filt, LR=d["L_R"] if sample else None,
+                                            eps_state=d["eps_state"], eps_obs=d["eps_obs"],
+                                            symmetrize=sym)
+            out = F.filter_smooth_fused(d["a"], d["mask"], d["A_K"], d["C_K"], d["Q"], d["R"],
+                                        d["m0"], d["P0"], alpha=alpha, L_R=d["L_R"],
+                                        eps_state=d["eps_state"], eps_obs=d["eps_obs"],
+                                        symmetrize=sym, want=TFI.NAMES)
+            tol = 5e-6 if dtype == torch.float32 else 1e-12
+            for k, want in zip(TFI.NAMES, tuple(filt) + tuple(smo)):
+                e = KC.rel_err(out[k], want)
+                assert e < tol, f"{k}: {e:.2e}"
+            desc += f" (dims {no},{po},{Ko})"
         elif kind == "smooth":
             KC.check_smooth(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=2000 + i,
                             sample=rng.random() < 0.7, symmetrize=sym, burn_in=burn)
