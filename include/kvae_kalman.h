@@ -348,9 +348,10 @@ typedef struct kvae_rollout {
 int kvae_predict_future(const kvae_dims *d, const kvae_rollout *io, void *stream);
 
 /* Filter and smoother in one call, the sequence of kvae/kalman_vae.py:141-160
- * (and of the imputation path kvae/evaluation.py:100-140): runs
- * kvae_filter_forward(d, f) and then kvae_smooth_forward(d, s) on `stream` (two
- * launches, every tensor written).  The smoother must read what the filter wrote:
+ * (and of the imputation path kvae/evaluation.py:100-140): the results of
+ * kvae_filter_forward(d, f) followed by kvae_smooth_forward(d, s) on `stream`, every
+ * tensor written (small state, 32768 sequences or more: one launch, see
+ * kvae_filter_smooth_fused; otherwise the two launches).  The smoother must read what the filter wrote:
  * s->mean_filt == f->mean_filt, s->cov_filt == f->cov_filt, s->mean_pred ==
  * f->mean_pred, s->cov_pred == f->cov_pred, s->mat_As == f->mat_As, s->mat_Cs ==
  * f->mat_Cs (KVAE_E_BADARG otherwise).  There is no fused backward entry point: between

@@ -523,6 +523,16 @@ int kvae_filter_smooth_forward(const kvae_dims* d, const kvae_filter_fwd* f,
         s->cov_filt != f->cov_filt || s->mean_pred != f->mean_pred ||
         s->cov_pred != f->cov_pred || s->mat_As != f->mat_As || s->mat_Cs != f->mat_Cs)
         return KVAE_E_BADARG;
+    // From 32768 sequences on (where the filter and the smoother would both run one lane per
+    // sequence anyway) the two sweeps are ONE launch: the reverse sweep re-mixes the per-step
+    // matrices and recomputes the predictions instead of reading back what the forward sweep
+    // wrote.  Below that the two four-lanes-per-sequence kernels are faster than one launch.
+    const char* e = getenv("KVAE_SEQ_LANES");
+    const int forced = e ? atoi(e) : 0;
+    if ((d->B >= 32768 && forced != 4) || forced == 1) {
+        const int rc1 = kvae_filter_smooth_fused(d, f, nullptr, s, nullptr, 0, stream);
+        if (rc1 != KVAE_E_UNSUPPORTED) return rc1;
+    }
     const int rc = kvae_filter_forward(d, f, stream);
     if (rc != KVAE_OK) return rc;
     return kvae_smooth_forward(d, s, stream);
