@@ -558,9 +558,16 @@ def run_imputation(args, rank, world, dev, rehearsal):
                 dom += " stage of one chunk"
                 res["kernels"] = {"masked_filter": {"us": tf * 1e6, "GBps": fb / tf / 1e9},
                                   "smoother": {"us": ts * 1e6, "GBps": sb / ts / 1e9}}
+        traffic = None
+        try:      # HBM bytes per launch counted by the PMC passes committed under profiles/
+            with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as fh:
+                traffic = json.load(fh).get(f"T{T}_B{chunk}_n{n}_p{p}_K{K}", {}).get(
+                    "filter_smooth_fused" if fused and args.net == "mlp" else "")
+        except OSError:
+            pass
         res["roofline"] = {"kernel": dom, "bound": "hbm",
                            "achieved": by / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": by / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "frac": by / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": by, "avg_launch_us": sec * 1e6}
     return res
 
