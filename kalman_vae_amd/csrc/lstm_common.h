@@ -49,4 +49,11 @@ __device__ __forceinline__ float2 load_streaming(const float* p) {
 }
 
 
+// many-tiles-per-workgroup form of the register-resident forward kernel (its own
+// translation unit, see lstm_resident.hip)
+int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, const float* x,
+                                 const float* Wih, const float* bias, const float* WhhT,
+                                 float* gates, float* h, float* c, const float* h_init,
+                                 const float* c_init, int store_gates, hipStream_t stream);
+
 }  // namespace kvae

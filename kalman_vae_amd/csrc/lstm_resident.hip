@@ -28,7 +28,7 @@ namespace kvae {
 constexpr int RH = 128;            // hidden size
 constexpr int RG4 = 4 * RH;
 constexpr int RLDA = RH + 2;       // LDS row stride of an h tile: rows 2 banks apart
-constexpr int RLDG = RG4 + 2;      // LDS row stride of a gate-gradient tile
+constexpr int RLDG [[maybe_unused]] = RG4 + 2;   // LDS row stride of a gate-gradient tile
 
 // Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every
 // outstanding global store of the wavefront (its release fence covers global memory);
@@ -59,7 +59,11 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
                      const float* __restrict__ h_init, const float* __restrict__ c_init,
                      float (&hbuf)[2][16 * RLDA]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
+#ifdef KVAE_LSTM_TILE_LOOP
+    const int u0 = 32 * wave, ub = u0 + 2 * cc;
+#else
     const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * cc;
+#endif
     const long BH = (long)B * RH, BG = (long)B * RG4;
 
     // this wavefront's slice of the recurrent matrix: w[gate][hf][kb] multiplies
@@ -75,6 +79,11 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
             w[g][1][kb] = v.y;
         }
     }
+#ifdef KVAE_LSTM_TILE_LOOP
+    // the workgroup works through tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the
+    // recurrent matrix loaded once
+    for (int r0 = 16 * blockIdx.x; r0 < B; r0 += 16 * gridDim.x) {
+#endif
     float cst[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -226,18 +235,30 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         lds_barrier();
 #endif
     }
+#ifdef KVAE_LSTM_TILE_LOOP
+    }
+#endif
 }
 
+#ifdef KVAE_LSTM_TILE_LOOP
+#define KVAE_FWD_KERNEL lstm128_resident_forward_tiles_kernel
+#else
+#define KVAE_FWD_KERNEL lstm128_resident_forward_kernel
+#endif
 template <int P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-lstm128_resident_forward_kernel(int T, int B, const float* __restrict__ x,
+KVAE_FWD_KERNEL(int T, int B, const float* __restrict__ x,
                                 const float* __restrict__ Wih, const float* __restrict__ bias,
                                 const float* __restrict__ WhhT,   // (H,4H)
                                 float* gates, float* __restrict__ h, float* __restrict__ c,
                                 const float* __restrict__ h_init,  // (B,H) or null
                                 const float* __restrict__ c_init, int store_gates) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][16 * RLDA];
+#ifdef KVAE_LSTM_TILE_LOOP
+    const bool full = (B & 15) == 0;
+#else
     const bool full = (int)blockIdx.x * 16 + 16 <= B;
+#endif
 #define KVAE_FWD_BODY(F_, G_) \
     lstm128_forward_body<P, F_, G_>(T, B, x, Wih, bias, WhhT, gates, h, c, h_init, c_init, hbuf)
     if (store_gates) {
@@ -247,6 +268,34 @@ lstm128_resident_forward_kernel(int T, int B, const float* __restrict__ x,
     }
 #undef KVAE_FWD_BODY
 }
+
+#ifdef KVAE_LSTM_TILE_LOOP
+// This translation unit is compiled a second time with KVAE_LSTM_TILE_LOOP for the
+// many-tiles-per-workgroup form of the forward kernel alone (in one translation unit the
+// two forms disturb each other's register allocation, and the single-tile form has none to
+// spare).
+int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, const float* x,
+                                 const float* Wih, const float* bias, const float* WhhT,
+                                 float* gates, float* h, float* c, const float* h_init,
+                                 const float* c_init, int store_gates, hipStream_t stream) {
+    const dim3 grid(workgroups);
+#define KVAE_R128T(P_)                                                                       \
+    hipLaunchKernelGGL(lstm128_resident_forward_tiles_kernel<P_>, grid, dim3(256), 0, stream, \
+                       T, B, x, Wih, bias, WhhT, gates, h, c, h_init, c_init, store_gates)
+    switch (P) {
+        case 0: KVAE_R128T(0); break;
+        case 1: KVAE_R128T(1); break;
+        case 2: KVAE_R128T(2); break;
+        case 3: KVAE_R128T(3); break;
+        case 4: KVAE_R128T(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_R128T
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+}  // namespace kvae
+#else   // the rest of the file: single-tile translation unit only
 
 // what the cell adjoint of one step reads from global memory for this lane's 4 rows x 2
 // units; independent of the recurrence, so loaded a step ahead
@@ -473,6 +522,21 @@ lstm128_resident_backward_kernel(int T, int B, const float* __restrict__ x,
 
 using namespace kvae;
 
+// workgroups that are resident at once: one per compute unit (each takes all registers)
+static int resident_workgroups() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n = cus;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 extern "C" {
 
 int kvae_lstm128_blocks(int B) { return B < 1 ? 0 : (B + 15) / 16; }
@@ -483,6 +547,17 @@ int kvae_lstm128_forward(int T, int B, int P, const void* x, const void* Wih, co
     if (T < 1 || B < 1 || !WhhT || !h || !c || (h_init == nullptr) != (c_init == nullptr) ||
         (P > 0 && (!x || !Wih || !bias)) || (P == 0 && !gates) || (store_gates && !gates))
         return KVAE_E_BADARG;
+    // A workgroup loads its 256 KB of the recurrent matrix once.  Over a whole sequence that
+    // is nothing; a one-step call over very many rows (the masked filter steps the network
+    // once per time step) would spend its time on those loads, so it gets one workgroup
+    // per compute unit, each working through many tiles.
+    if (T < 8 && (B + 15) / 16 > 2 * resident_workgroups())
+        return launch_lstm128_forward_tiles(T, B, P, resident_workgroups(), (const float*)x,
+                                            (const float*)Wih, (const float*)bias,
+                                            (const float*)WhhT, (float*)gates, (float*)h,
+                                            (float*)c, (const float*)h_init,
+                                            (const float*)c_init, store_gates,
+                                            (hipStream_t)stream);
     const dim3 grid((B + 15) / 16);
 #define KVAE_R128F(P_)                                                                           \
     hipLaunchKernelGGL(lstm128_resident_forward_kernel<P_>, grid, dim3(256), 0,                  \
@@ -527,3 +602,4 @@ int kvae_lstm128_backward(int T, int B, int P, const void* x, const void* Wih, c
 }
 
 }  // extern "C"
+#endif   // KVAE_LSTM_TILE_LOOP

@@ -441,6 +441,22 @@ def lstm2_nograd(x, lstm, hidden=None):
     h_init = c_init = None
     if hidden is not None:
         h_init, c_init = hidden[0].contiguous(), hidden[1].contiguous()
+    if RESIDENT:
+        # one launch per layer with the layer's recurrent matrix resident in registers (a
+        # one-step call over many rows works through them with one workgroup per compute
+        # unit), layer 1's input projection as one library GEMM in between
+        stream = capi.current_stream_ptr()
+        init = lambda t, l: None if t is None else t[l].data_ptr()
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, P, x.data_ptr(), keep[0].data_ptr(), b0.data_ptr(), whh0t.data_ptr(), None,
+            h0.data_ptr(), c0.data_ptr(), init(h_init, 0), init(c_init, 0), 0, stream))
+        gates1 = torch.addmm(b1, h0.view(T * B, H), wih1t)
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
+            c1.data_ptr(), init(h_init, 1), init(c_init, 1), 0, stream))
+        if T == 1:
+            return h1, (h_n, c_n)
+        return h1, (torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]]))
     capi.check(lib.kvae_lstm2_forward(
         T, B, P, x.data_ptr(), *(k.data_ptr() for k in keep), None, h0.data_ptr(), c0.data_ptr(),
         None, h1.data_ptr(), c1.data_ptr(), capi.ptr(h_init), capi.ptr(c_init),

@@ -162,3 +162,49 @@ def test_resident_layer_with_carried_state_matches_torch(T, B, P):
     names = ["x"] + [n for n, _ in lstm.named_parameters()]
     bad = [(n, rel_err(got[n], g)) for n, g in zip(names, gref) if not rel_err(got[n], g) < 1e-4]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("T,B,P,gates", [(1, 16 * 700 + 5, 2, 0), (1, 16 * 700, 0, 0),
+                                         (3, 16 * 530 + 9, 0, 1), (2, 16 * 600, 3, 1)])
+def test_resident_layer_many_tiles_per_workgroup_matches_torch(T, B, P, gates):
+    """Short sequences over many rows launch one workgroup per compute unit, each working
+    through several 16-row tiles with the recurrent matrix loaded once: outputs (and the
+    stored gates) against torch.nn.LSTM from a carried (h, c), full and ragged last tile."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(T + B + P)
+    dev = torch.device("cuda:0")
+    H = 128
+    in_dim = P if P > 0 else H
+    lstm = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev)
+    x = torch.randn(T, B, in_dim, device=dev)
+    h_in, c_in = 0.5 * torch.randn(1, B, H, device=dev), 0.5 * torch.randn(1, B, H, device=dev)
+    with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+        ref, (hn, cn) = lstm(x, (h_in, c_in))
+    w_ih, w_hh = lstm.weight_ih_l0.detach(), lstm.weight_hh_l0.detach()
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().contiguous()
+    whht = w_hh.t().contiguous()
+    new = lambda *s: torch.full(s, float("nan"), device=dev)
+    g_buf, h, c = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+    st = torch.cuda.current_stream().cuda_stream
+    hi, ci = h_in[0].contiguous(), c_in[0].contiguous()
+    if P == 0:
+        g_buf.copy_(torch.addmm(bias, x.view(T * B, H), w_ih.t()).view(T, B, 4 * H))
+        rc = lib.kvae_lstm128_forward(T, B, 0, None, None, None, whht.data_ptr(), g_buf.data_ptr(),
+                                      h.data_ptr(), c.data_ptr(), hi.data_ptr(), ci.data_ptr(),
+                                      gates, st)
+    else:
+        rc = lib.kvae_lstm128_forward(T, B, P, x.contiguous().data_ptr(),
+                                      w_ih.contiguous().data_ptr(), bias.data_ptr(),
+                                      whht.data_ptr(), g_buf.data_ptr() if gates else None,
+                                      h.data_ptr(), c.data_ptr(), hi.data_ptr(), ci.data_ptr(),
+                                      gates, st)
+    assert rc == 0
+    assert rel_err(h, ref) < 1e-5
+    assert rel_err(h[-1], hn[0]) < 1e-5 and rel_err(c[-1], cn[0]) < 1e-5
+    if gates:
+        # the activated gates of the last step reproduce its cell update
+        i_g, f_g, g_g, o_g = g_buf[-1].split(H, dim=-1)
+        c_prev = c[-2] if T > 1 else ci
+        assert rel_err(f_g * c_prev + i_g * g_g, c[-1]) < 1e-5
+        assert rel_err(o_g * torch.tanh(c[-1]), h[-1]) < 1e-5
