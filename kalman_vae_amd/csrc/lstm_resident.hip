@@ -80,10 +80,24 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         }
     }
 #ifdef KVAE_LSTM_TILE_LOOP
-    // the workgroup works through tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the
-    // recurrent matrix loaded once
-    for (int r0 = 16 * blockIdx.x; r0 < B; r0 += 16 * gridDim.x) {
-#endif
+    // The workgroup works through tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the
+    // recurrent matrix loaded once.  A tile's carried state and its first step's inputs are
+    // requested while the previous tile computes (hv / cv / gx below).
+    const int tile_stride = 16 * gridDim.x;
+    float2 hv[4], cv[4];
+    auto load_state = [&](int rb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rb + 4 * s + i;
+            hv[i] = cv[i] = make_float2(0.f, 0.f);
+            if (c_init && (FULL || row < B))
+                cv[i] = *reinterpret_cast<const float2*>(c_init + (long)row * RH + ub);
+            if (h_init && (FULL || row < B))
+                hv[i] = *reinterpret_cast<const float2*>(h_init + (long)row * RH + ub);
+        }
+    };
+    load_state(16 * blockIdx.x);
+#else
     float cst[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -101,6 +115,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         *reinterpret_cast<float2*>(&hbuf[1][lr * RLDA + ub]) = v;
     }
     __syncthreads();
+#endif
 
     float wx[4][2][P > 0 ? P : 1], bs[4][2];
     if (P > 0) {
@@ -115,7 +130,11 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         }
     }
     // input projection of a step for this lane's rows and units
+#ifdef KVAE_LSTM_TILE_LOOP
+    auto load_gx_at = [&](int r0, int t, GateRows& gx) {
+#else
     auto load_gx = [&](int t, GateRows& gx) {
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 4 * s + i;
@@ -145,7 +164,23 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
     };
 
     GateRows gx;
+#ifdef KVAE_LSTM_TILE_LOOP
+    load_gx_at(16 * blockIdx.x, 0, gx);
+    for (int r0 = 16 * blockIdx.x; r0 < B; r0 += tile_stride) {
+    const bool has_next = r0 + tile_stride < B;
+    float cst[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cst[i][0] = cv[i].x;
+        cst[i][1] = cv[i].y;
+        *reinterpret_cast<float2*>(&hbuf[1][(4 * s + i) * RLDA + ub]) = hv[i];
+    }
+    __syncthreads();
+    if (has_next) load_state(r0 + tile_stride);
+    auto load_gx = [&](int t, GateRows& g_) { load_gx_at(r0, t, g_); };
+#else
     load_gx(0, gx);
+#endif
     for (int t = 0; t < T; ++t) {
         f32x4 acc[4][2];
 #pragma unroll
@@ -159,7 +194,15 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         // the next step's input projection does not depend on the recurrence: its loads
         // are in flight while this step's matrix instructions run
         // (the last step loads its own inputs again rather than branch)
+#ifdef KVAE_LSTM_TILE_LOOP
+        if (t + 1 < T) {
+            load_gx(t + 1, gx);
+        } else if (has_next) {
+            load_gx_at(r0 + tile_stride, 0, gx);      // the next tile's first step
+        }
+#else
         load_gx(t + 1 < T ? t + 1 : t, gx);
+#endif
         float2 res[4][6];
         auto activate = [&](int i, int hf) {
 #ifdef KVAE_EXP_NOACT
