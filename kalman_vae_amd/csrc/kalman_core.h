@@ -39,6 +39,43 @@ enum : int {
 };
 
 // ---------------------------------------------------------------------------
+// Reciprocal, reciprocal square root and natural logarithm of a pivot.
+// fp32 device code uses the hardware approximations (v_rcp_f32, v_rsq_f32,
+// v_log_f32: 1 ulp on normal numbers, one instruction each) instead of the
+// correctly rounded division / sqrt / log sequences, which are 10-15 dependent
+// instructions around a quarter-rate operation and sat on the serial chain of
+// every time step.  Pivots are O(1) positive numbers (a non-positive pivot is
+// replaced by 1 before it gets here), so the denormal and range fix-ups those
+// sequences add are not needed.  fp64 and the host build keep IEEE arithmetic.
+// ---------------------------------------------------------------------------
+KV_HD float recip(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+KV_HD double recip(double x) { return 1.0 / x; }
+
+KV_HD float rsqrt_pos(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+KV_HD double rsqrt_pos(double x) { return 1.0 / sqrt(x); }
+
+KV_HD float log_pos(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_logf(x) * 0.693147180559945309f;   // v_log_f32 is log2
+#else
+    return logf(x);
+#endif
+}
+KV_HD double log_pos(double x) { return log(x); }
+
+// ---------------------------------------------------------------------------
 // Fixed-size dense helpers on row-major register arrays.
 // ---------------------------------------------------------------------------
 
@@ -163,9 +200,8 @@ KV_HD bool cholesky(const R* S, R* L) {
             ok = false;
             d = R(1);
         }
-        const R ljj = sqrt(d);
-        const R inv = R(1) / ljj;
-        L[j * N + j] = ljj;
+        const R inv = rsqrt_pos(d);
+        L[j * N + j] = d * inv;
         KV_UNROLL
         for (int i = j + 1; i < N; ++i) {
             R s = S[i * N + j];
@@ -183,21 +219,17 @@ KV_HD bool cholesky(const R* S, R* L) {
 template <typename R, int N>
 KV_HD void tri_lower_inverse(const R* L, R* Li) {
     KV_UNROLL
+    for (int i = 0; i < N; ++i) Li[i * N + i] = recip(L[i * N + i]);
+    KV_UNROLL
     for (int j = 0; j < N; ++j) {
         KV_UNROLL
-        for (int i = 0; i < N; ++i) {
-            if (i < j) {
-                Li[i * N + j] = R(0);
-            } else if (i == j) {
-                Li[i * N + j] = R(1) / L[i * N + i];
-            }
-        }
+        for (int i = 0; i < j; ++i) Li[i * N + j] = R(0);
         KV_UNROLL
         for (int i = j + 1; i < N; ++i) {
             R s = R(0);
             KV_UNROLL
             for (int k = j; k < i; ++k) s += L[i * N + k] * Li[k * N + j];
-            Li[i * N + j] = -s / L[i * N + i];
+            Li[i * N + j] = -s * Li[i * N + i];
         }
     }
 }
@@ -223,7 +255,7 @@ KV_HD void solve_lower(const R* L, R* x) {
         R s = x[i];
         KV_UNROLL
         for (int k = 0; k < i; ++k) s -= L[i * N + k] * x[k];
-        x[i] = s / L[i * N + i];
+        x[i] = s * recip(L[i * N + i]);
     }
 }
 // x := L^-T x (back substitution).
@@ -234,7 +266,7 @@ KV_HD void solve_lower_t(const R* L, R* x) {
         R s = x[i];
         KV_UNROLL
         for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
-        x[i] = s / L[i * N + i];
+        x[i] = s * recip(L[i * N + i]);
     }
 }
 
@@ -532,8 +564,9 @@ KV_HD void mlp2_softmax(const R* net, int hidden, const R* a, R* w) {
         w[k] = exp(logit[k] - top);
         total += w[k];
     }
+    const R inv_total = recip(total);
     KV_UNROLL
-    for (int k = 0; k < K; ++k) w[k] /= total;
+    for (int k = 0; k < K; ++k) w[k] *= inv_total;
 }
 
 template <typename R>
@@ -1229,7 +1262,7 @@ KV_HD R gauss_logpdf(const R* L, R* r, bool want_u) {
     R q = vdot<R, D>(r, r);
     R hl = R(0);
     KV_UNROLL
-    for (int i = 0; i < D; ++i) hl += log(L[i * D + i]);
+    for (int i = 0; i < D; ++i) hl += log_pos(L[i * D + i]);
     if (want_u) solve_lower_t<R, D>(L, r);
     return R(-0.5) * (R(D) * log_2pi<R>() + q) - hl;
 }
@@ -1277,7 +1310,7 @@ KV_HD void elbo_forward_pair(const ElboFwdArgs<R>& g, int t, int b) {
     {
         R hl = R(0);
         KV_UNROLL
-        for (int i = 0; i < N; ++i) hl += log(L[i * N + i]);
+        for (int i = 0; i < N; ++i) hl += log_pos(L[i * N + i]);
         g.post[tb] = R(-0.5) * (R(N) * log_2pi<R>() + vdot<R, N>(e, e)) - hl;
     }
     if (st && g.status) {
@@ -1405,7 +1438,7 @@ KV_HD void elbo_backward_pair(const ElboBwdArgs<R>& g, int t, int b, R* acc) {
         vzero<R, N * N>(Psb);
         outer_add<R, N, N>(R(1), zb, e, Lb);
         KV_UNROLL
-        for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp / L[i * N + i];
+        for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp * recip(L[i * N + i]);
         cholesky_adjoint_add<R, N>(L, Lb, Psb);
         gstore<R, N * N>(g.d_Ps + tb * N * N, Psb);
     }

@@ -111,7 +111,7 @@ template <typename R, int D>
 KV_HD R half_logdet(const R* L) {
     R s = R(0);
     KV_UNROLL
-    for (int i = 0; i < D; ++i) s += log(L[i * D + i]);
+    for (int i = 0; i < D; ++i) s += log_pos(L[i * D + i]);
     return s;
 }
 
@@ -372,7 +372,7 @@ KV_HD void loss_backward_sequence(const LossBwdArgs<R>& g, int b, R* acc) {
             vzero<R, N * N>(Lb);
             outer_add<R, N, N>(R(1), zb, e, Lb);
             KV_UNROLL
-            for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp / L[i * N + i];
+            for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp * recip(L[i * N + i]);
             cholesky_adjoint_add<R, N>(L, Lb, Psb);
         }
         // C-part of d_alpha[t]; basis gradient of C

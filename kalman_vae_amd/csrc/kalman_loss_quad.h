@@ -336,7 +336,7 @@ KQ_DEV void loss_backward_quad(const LossBwdArgs<R>& g, int b, bool active,
             vzero<R, N * N>(Sadd);
             outer_add<R, N, N>(R(1), zb, e, Lb);
             KV_UNROLL
-            for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp / L[i * N + i];
+            for (int i = 0; i < N; ++i) Lb[i * N + i] -= wp * recip(L[i * N + i]);
             cholesky_adjoint_add<R, N>(L, Lb, Sadd);
             QM<R, N, N> Sq;
             qscatter<R, N, N>(Sadd, Sq);
