@@ -484,6 +484,15 @@ int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, co
  *   first axis is [ db | db (4H each: bias_ih and bias_hh) | dWih (4H,P) ]; for P > 0 also
  *   dx (T,B,P) = dG Wih.                                                                */
 int kvae_lstm128_blocks(int B);
+/* How the two kernels above form their matrix products.  split = 1 (the default): every
+ * fp32 product a*b is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo on the bf16 matrix instruction with
+ * fp32 accumulation (x = x_hi + x_lo, both bf16): about 1e-5 relative per product, 1e-6 on
+ * a 128-term gate sum, a fifth of the matrix-instruction time.  split = 0: the fp32 matrix
+ * instruction, exact fp32 products.  KVAE_LSTM_PRECISION=fp32 in the environment selects 0
+ * at the first call.  Process-wide; no counterpart in the reference (torch.nn.LSTM's
+ * precision is the library's).                                                          */
+int kvae_lstm128_set_precision(int split);
+int kvae_lstm128_get_precision(void);
 int kvae_lstm128_forward(int T, int B, int P, const void *x, const void *Wih, const void *bias,
                          const void *WhhT, void *gates, void *h, void *c, const void *h_init,
                          const void *c_init, int store_gates, void *stream);

@@ -49,11 +49,22 @@ __device__ __forceinline__ float2 load_streaming(const float* p) {
 }
 
 
-// many-tiles-per-workgroup form of the register-resident forward kernel (its own
-// translation unit, see lstm_resident.hip)
-int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, const float* x,
-                                 const float* Wih, const float* bias, const float* WhhT,
-                                 float* gates, float* h, float* c, const float* h_init,
-                                 const float* c_init, int store_gates, hipStream_t stream);
+// Launchers of the register-resident layer kernels (lstm_resident.hip is compiled four
+// times: exact fp32 or split-bf16 products, one tile or many tiles per workgroup; the
+// many-tiles builds hold the forward kernel only).
+#define KVAE_LSTM128_FWD_ARGS                                                                   \
+    const float *x, const float *Wih, const float *bias, const float *WhhT, float *gates,       \
+        float *h, float *c, const float *h_init, const float *c_init, int store_gates,          \
+        hipStream_t stream
+#define KVAE_LSTM128_BWD_ARGS                                                                   \
+    const float *x, const float *Wih, const float *gates, const float *c, const float *c_init,  \
+        const float *g_h, const float *Whh, float *dG, float *dx, float *partial,               \
+        hipStream_t stream
+int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, KVAE_LSTM128_FWD_ARGS);
+int launch_lstm128_forward_tiles_split(int T, int B, int P, int workgroups, KVAE_LSTM128_FWD_ARGS);
+int launch_lstm128_forward_exact(int T, int B, int P, KVAE_LSTM128_FWD_ARGS);
+int launch_lstm128_forward_split(int T, int B, int P, KVAE_LSTM128_FWD_ARGS);
+int launch_lstm128_backward_exact(int T, int B, int P, KVAE_LSTM128_BWD_ARGS);
+int launch_lstm128_backward_split(int T, int B, int P, KVAE_LSTM128_BWD_ARGS);
 
 }  // namespace kvae

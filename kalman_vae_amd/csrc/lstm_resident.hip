@@ -20,6 +20,9 @@
 // computes it for all steps with one library GEMM and passes it in `gates`.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "../../include/kvae_kalman.h"
 #include "lstm_common.h"
 
@@ -27,7 +30,7 @@ namespace kvae {
 
 constexpr int RH = 128;            // hidden size
 constexpr int RG4 = 4 * RH;
-constexpr int RLDA = RH + 2;       // LDS row stride of an h tile: rows 2 banks apart
+constexpr int RLDA [[maybe_unused]] = RH + 2;   // LDS row stride of an h tile: rows 2 banks apart
 constexpr int RLDG [[maybe_unused]] = RG4 + 2;   // LDS row stride of a gate-gradient tile
 
 // Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every
@@ -43,6 +46,54 @@ struct GateRows {                  // one lane's 4 rows x 2 units of the four ga
     float2 v[4][4];                // [row][gate]
 };
 
+#ifdef KVAE_LSTM_BF16X3
+// Split-precision build of this translation unit.  The fp32 matrix instruction
+// (16x16x4, 32 cycles) is replaced by three bf16 ones (16x16x32, 16 cycles each, eight
+// times the depth): with x = x_hi + x_lo, both bf16, x_lo = bf16(x - x_hi),
+//     a b  ~  a_hi b_hi + a_lo b_hi + a_hi b_lo          (accumulated in fp32)
+// drops a_lo b_lo and the two representation residuals, each below 2^-17 |a b|: a product
+// is good to about 1e-5 relative (fp32: 6e-8), a 128-term gate sum to about 1e-6 of the sum
+// of its terms' magnitudes.  Operands use the same registers as the fp32 form (a hi and a
+// lo bf16 per fp32 value); a step needs 96 matrix instructions of 16 cycles instead of 256
+// of 32.  The kernels of this build carry `split` in their names.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int RLDB = RH + 8;       // bf16 elements per LDS row of an h tile (272 B: rows 4 banks apart)
+constexpr int RLDGB [[maybe_unused]] = RG4 + 8;   // ... of a gate-gradient tile (1040 B)
+
+// (x, y) -> packed bf16 pairs hi = (bf16 x, bf16 y), lo = (bf16 (x - hi.x), bf16 (y - hi.y))
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& hi, unsigned& lo) {
+    const f32x2v v = {x, y};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2v r = {x - __builtin_bit_cast(float, hi << 16),
+                      y - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+// eight fp32 values -> the hi and lo operand registers of one lane
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(x[2 * j], x[2 * j + 1], h[j], l[j]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+    hi = __builtin_bit_cast(bf16x8, hv);
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+// a tile in LDS as its hi and lo halves
+template <int ELEMS>
+struct SplitTile {
+    __bf16 hi[ELEMS], lo[ELEMS];
+};
+typedef SplitTile<16 * RLDB> HTile;
+typedef SplitTile<16 * RLDGB> GTile;
+#define KVAE_HBUF_T HTile (&hbuf)[2]
+#define KVAE_GTILE_T GTile (&tile)[2]
+#else
+#define KVAE_HBUF_T float (&hbuf)[2][16 * RLDA]
+#define KVAE_GTILE_T float (&tile)[2][16 * RLDG]
+#endif
+
 // grid = ceil(B/16), block = 256.  P > 0: the layer input x (T,B,P) with Wih (4H,P) and
 // bias (4H) = b_ih + b_hh is projected in the kernel; P == 0: gates (T,B,4H) holds the
 // input projection (bias included) on entry.  With store_gates the activated gates of
@@ -57,7 +108,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
                      const float* __restrict__ bias, const float* __restrict__ WhhT, float* gates,
                      float* __restrict__ h, float* __restrict__ c,
                      const float* __restrict__ h_init, const float* __restrict__ c_init,
-                     float (&hbuf)[2][16 * RLDA]) {
+                     KVAE_HBUF_T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
 #ifdef KVAE_LSTM_TILE_LOOP
     const int u0 = 32 * wave, ub = u0 + 2 * cc;
@@ -66,6 +117,35 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
 #endif
     const long BH = (long)B * RH, BG = (long)B * RG4;
 
+#ifdef KVAE_LSTM_BF16X3
+    // this wavefront's slice of the recurrent matrix as B operands of the 16x16x32
+    // instruction: w*[gate][hf][kk][j] multiplies h[., 32 kk + 8 s + j] into the gate
+    // pre-activation of unit ub + hf
+    bf16x8 whi[4][2][4], wlo[4][2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 v = *reinterpret_cast<const float2*>(
+                    WhhT + (long)(32 * kk + 8 * s + j) * RG4 + g * RH + ub);
+                v0[j] = v.x;
+                v1[j] = v.y;
+            }
+            split8(v0, whi[g][0][kk], wlo[g][0][kk]);
+            split8(v1, whi[g][1][kk], wlo[g][1][kk]);
+        }
+    }
+    // h of a row's two adjacent units -> the tile the next step reads its A operands from
+    auto put_h = [&](int buf, int lr, float2 v) {
+        unsigned hi, lo;
+        split_pair(v.x, v.y, hi, lo);
+        *reinterpret_cast<unsigned*>(&hbuf[buf].hi[lr * RLDB + ub]) = hi;
+        *reinterpret_cast<unsigned*>(&hbuf[buf].lo[lr * RLDB + ub]) = lo;
+    };
+#else
     // this wavefront's slice of the recurrent matrix: w[gate][hf][kb] multiplies
     // h[., 4 kb + s] into the gate pre-activation of unit ub + hf
     float w[4][2][32];
@@ -79,6 +159,10 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
             w[g][1][kb] = v.y;
         }
     }
+    auto put_h = [&](int buf, int lr, float2 v) {
+        *reinterpret_cast<float2*>(&hbuf[buf][lr * RLDA + ub]) = v;
+    };
+#endif
 #ifdef KVAE_LSTM_TILE_LOOP
     // The workgroup works through tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the
     // recurrent matrix loaded once.  A tile's carried state and its first step's inputs are
@@ -112,7 +196,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         float2 v = {0.f, 0.f};
         if (h_init && (FULL || row < B))
             v = *reinterpret_cast<const float2*>(h_init + (long)row * RH + ub);
-        *reinterpret_cast<float2*>(&hbuf[1][lr * RLDA + ub]) = v;
+        put_h(1, lr, v);
     }
     __syncthreads();
 #endif
@@ -173,7 +257,7 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
     for (int i = 0; i < 4; ++i) {
         cst[i][0] = cv[i].x;
         cst[i][1] = cv[i].y;
-        *reinterpret_cast<float2*>(&hbuf[1][(4 * s + i) * RLDA + ub]) = hv[i];
+        put_h(1, 4 * s + i, hv[i]);
     }
     __syncthreads();
     if (has_next) load_state(r0 + tile_stride);
@@ -225,6 +309,36 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
                 res[i][4].y = hn; res[i][5].y = cn;
             }
         };
+#ifdef KVAE_LSTM_BF16X3
+        {
+            // the step's A operands: row cc of the h tile, elements 32 kk + 8 s .. + 7, hi and lo
+            const int a_off = cc * RLDB + 8 * s;
+            bf16x8 ah[4], al[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                ah[kk] = *reinterpret_cast<const bf16x8*>(&hbuf[(t + 1) & 1].hi[a_off + 32 * kk]);
+                al[kk] = *reinterpret_cast<const bf16x8*>(&hbuf[(t + 1) & 1].lo[a_off + 32 * kk]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define KVAE_X3(HF_, KK_)                                                                          \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[g][HF_] =                                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[KK_], whi[g][HF_][KK_], acc[g][HF_], 0, 0, 0);  \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[g][HF_] =                                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[KK_], whi[g][HF_][KK_], acc[g][HF_], 0, 0, 0);  \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[g][HF_] =                                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[KK_], wlo[g][HF_][KK_], acc[g][HF_], 0, 0, 0)
+            // first unit of each pair
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { KVAE_X3(0, kk); }
+            // second unit, with the gate activations of the first unit between the groups
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                KVAE_X3(1, kk);
+                activate(kk, 0);
+            }
+#undef KVAE_X3
+        }
+#else
         {
             // all of the step's A operands are requested before the first matrix instruction
             // (the compiler would otherwise sink each LDS read to its use and expose the
@@ -250,13 +364,13 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
                 if ((kb & 7) == 3) activate(kb >> 3, 0);
             }
         }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) activate(i, 1);
-        float* h_tile = hbuf[t & 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int lr = 4 * s + i, row = r0 + lr;
-            *reinterpret_cast<float2*>(h_tile + lr * RLDA + ub) = res[i][4];
+            put_h(t & 1, lr, res[i][4]);
 #ifndef KVAE_EXP_NOSTORE
             if (FULL || row < B) {
                 const long o = (long)row * RH + ub;
@@ -283,10 +397,27 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
 #endif
 }
 
+// kernel and launcher names of the four builds of this file
+#ifdef KVAE_LSTM_BF16X3
+#ifdef KVAE_LSTM_TILE_LOOP
+#define KVAE_FWD_KERNEL lstm128_split_forward_tiles_kernel
+#else
+#define KVAE_FWD_KERNEL lstm128_split_forward_kernel
+#endif
+#define KVAE_BWD_KERNEL lstm128_split_backward_kernel
+#define KVAE_LAUNCH_TILES launch_lstm128_forward_tiles_split
+#define KVAE_LAUNCH_FWD launch_lstm128_forward_split
+#define KVAE_LAUNCH_BWD launch_lstm128_backward_split
+#else
 #ifdef KVAE_LSTM_TILE_LOOP
 #define KVAE_FWD_KERNEL lstm128_resident_forward_tiles_kernel
 #else
 #define KVAE_FWD_KERNEL lstm128_resident_forward_kernel
+#endif
+#define KVAE_BWD_KERNEL lstm128_resident_backward_kernel
+#define KVAE_LAUNCH_TILES launch_lstm128_forward_tiles
+#define KVAE_LAUNCH_FWD launch_lstm128_forward_exact
+#define KVAE_LAUNCH_BWD launch_lstm128_backward_exact
 #endif
 template <int P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -296,7 +427,11 @@ KVAE_FWD_KERNEL(int T, int B, const float* __restrict__ x,
                                 float* gates, float* __restrict__ h, float* __restrict__ c,
                                 const float* __restrict__ h_init,  // (B,H) or null
                                 const float* __restrict__ c_init, int store_gates) {
+#ifdef KVAE_LSTM_BF16X3
+    __shared__ __attribute__((aligned(16))) HTile hbuf[2];
+#else
     __shared__ __attribute__((aligned(16))) float hbuf[2][16 * RLDA];
+#endif
 #ifdef KVAE_LSTM_TILE_LOOP
     const bool full = (B & 15) == 0;
 #else
@@ -317,13 +452,13 @@ KVAE_FWD_KERNEL(int T, int B, const float* __restrict__ x,
 // many-tiles-per-workgroup form of the forward kernel alone (in one translation unit the
 // two forms disturb each other's register allocation, and the single-tile form has none to
 // spare).
-int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, const float* x,
-                                 const float* Wih, const float* bias, const float* WhhT,
-                                 float* gates, float* h, float* c, const float* h_init,
-                                 const float* c_init, int store_gates, hipStream_t stream) {
+int KVAE_LAUNCH_TILES(int T, int B, int P, int workgroups, const float* x,
+                      const float* Wih, const float* bias, const float* WhhT,
+                      float* gates, float* h, float* c, const float* h_init,
+                      const float* c_init, int store_gates, hipStream_t stream) {
     const dim3 grid(workgroups);
 #define KVAE_R128T(P_)                                                                       \
-    hipLaunchKernelGGL(lstm128_resident_forward_tiles_kernel<P_>, grid, dim3(256), 0, stream, \
+    hipLaunchKernelGGL(KVAE_FWD_KERNEL<P_>, grid, dim3(256), 0, stream,                      \
                        T, B, x, Wih, bias, WhhT, gates, h, c, h_init, c_init, store_gates)
     switch (P) {
         case 0: KVAE_R128T(0); break;
@@ -358,11 +493,28 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                       const float* __restrict__ c_init, const float* __restrict__ g_h,
                       const float* __restrict__ Whh, float* __restrict__ dG,
                       float* __restrict__ dx, float* __restrict__ partial,
-                      float (&tile)[2][16 * RLDG], float (&dx_part)[2][4][16][P > 0 ? P : 1]) {
+                      KVAE_GTILE_T, float (&dx_part)[2][4][16][P > 0 ? P : 1]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
     const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * cc;
     const long BH = (long)B * RH, BG = (long)B * RG4;
 
+#ifdef KVAE_LSTM_BF16X3
+    // w*[hf][kk][j] multiplies dG[., 32 kk + 8 s + j] into dh of unit ub + hf
+    bf16x8 whi[2][16], wlo[2][16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 v =
+                *reinterpret_cast<const float2*>(Whh + (long)(32 * kk + 8 * s + j) * RH + ub);
+            v0[j] = v.x;
+            v1[j] = v.y;
+        }
+        split8(v0, whi[0][kk], wlo[0][kk]);
+        split8(v1, whi[1][kk], wlo[1][kk]);
+    }
+#else
     // w[hf][kb] multiplies dG[., 4 kb + s] into dh of unit ub + hf
     float w[2][128];
 #pragma unroll
@@ -371,6 +523,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
         w[0][kb] = v.x;
         w[1][kb] = v.y;
     }
+#endif
     float dc[4][2], sb[4][2], sw[4][2][P > 0 ? P : 1], wx[4][2][P > 0 ? P : 1];
     f32x4 rec[2];
 #pragma unroll
@@ -417,7 +570,9 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     CellRows in;
     load_rows(T - 1, in);
     for (int t = T - 1; t >= 0; --t) {
+#ifndef KVAE_LSTM_BF16X3
         float* g_tile = tile[t & 1];
+#endif
         float2 dgs[4][4];   // this step's gate gradients, stored during the matrix loop
         float xv[4][P > 0 ? P : 1];
         if (P > 0) {
@@ -455,12 +610,22 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             dgs[i][1] = df;
             dgs[i][2] = dg;
             dgs[i][3] = dout;
+            const float2 dgt[4] = {di, df, dg, dout};
+#ifdef KVAE_LSTM_BF16X3
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned hi, lo;
+                split_pair(dgt[g].x, dgt[g].y, hi, lo);
+                *reinterpret_cast<unsigned*>(&tile[t & 1].hi[lr * RLDGB + g * RH + ub]) = hi;
+                *reinterpret_cast<unsigned*>(&tile[t & 1].lo[lr * RLDGB + g * RH + ub]) = lo;
+            }
+#else
             float* tl = g_tile + lr * RLDG + ub;
             *reinterpret_cast<float2*>(tl) = di;
             *reinterpret_cast<float2*>(tl + RH) = df;
             *reinterpret_cast<float2*>(tl + 2 * RH) = dg;
             *reinterpret_cast<float2*>(tl + 3 * RH) = dout;
-            const float2 dgt[4] = {di, df, dg, dout};
+#endif
             float dxp[P > 0 ? P : 1];
 #pragma unroll
             for (int q = 0; q < P; ++q) dxp[q] = 0.f;
@@ -501,6 +666,38 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             const int i = idx >> 2, g = idx & 3;
             if (FULL || r0 + 4 * s + i < B) store_streaming(dG + t * BG + (long)(r0 + 4 * s + i) * RG4 + g * RH + ub, dgs[i][g]);
         };
+#ifdef KVAE_LSTM_BF16X3
+        if (t > 0) {
+            // A operands: row cc of the gate-gradient tile, elements 32 kk + 8 s .. + 7; read
+            // two k-groups ahead of the matrix instructions that use them
+            const int a_off = cc * RLDGB + 8 * s;
+            bf16x8 ah[2][2], al[2][2];
+            auto read_group = [&](int grp, bf16x8 (&h_)[2], bf16x8 (&l_)[2]) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    h_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].hi[a_off + 32 * (2 * grp + q)]);
+                    l_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].lo[a_off + 32 * (2 * grp + q)]);
+                }
+            };
+            read_group(0, ah[0], al[0]);
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {
+                if (grp < 7) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int kk = 2 * grp + q;
+                    rec[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], whi[0][kk], rec[0], 0, 0, 0);
+                    rec[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], whi[1][kk], rec[1], 0, 0, 0);
+                    rec[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[grp & 1][q], whi[0][kk], rec[0], 0, 0, 0);
+                    rec[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[grp & 1][q], whi[1][kk], rec[1], 0, 0, 0);
+                    rec[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], wlo[0][kk], rec[0], 0, 0, 0);
+                    rec[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], wlo[1][kk], rec[1], 0, 0, 0);
+                    store_dg(kk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#else
         if (t > 0) {
             const float* a_row = g_tile + cc * RLDG + s;
 #pragma unroll
@@ -514,6 +711,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                 }
             }
         } else {
+#endif
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) store_dg(idx);
         }
@@ -547,13 +745,17 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
 
 template <int P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-lstm128_resident_backward_kernel(int T, int B, const float* __restrict__ x,
+KVAE_BWD_KERNEL(int T, int B, const float* __restrict__ x,
                                  const float* __restrict__ Wih, const float* __restrict__ gates,
                                  const float* __restrict__ cg, const float* __restrict__ c_init,
                                  const float* __restrict__ g_h, const float* __restrict__ Whh,
                                  float* __restrict__ dG, float* __restrict__ dx,
                                  float* __restrict__ partial) {
+#ifdef KVAE_LSTM_BF16X3
+    __shared__ __attribute__((aligned(16))) GTile tile[2];
+#else
     __shared__ __attribute__((aligned(16))) float tile[2][16 * RLDG];
+#endif
     __shared__ float dx_part[2][4][16][P > 0 ? P : 1];
     // (one body for full and ragged tiles: a second, unpredicated instance costs registers
     // the resident matrix needs)
@@ -561,8 +763,48 @@ lstm128_resident_backward_kernel(int T, int B, const float* __restrict__ x,
                                     tile, dx_part);
 }
 
+// single-tile launchers of this build (the C entry points below pick a build)
+int KVAE_LAUNCH_FWD(int T, int B, int P, const float* x, const float* Wih, const float* bias,
+                    const float* WhhT, float* gates, float* h, float* c, const float* h_init,
+                    const float* c_init, int store_gates, hipStream_t stream) {
+    const dim3 grid((B + 15) / 16);
+#define KVAE_R128F(P_)                                                                   \
+    hipLaunchKernelGGL(KVAE_FWD_KERNEL<P_>, grid, dim3(256), 0, stream, T, B, x, Wih, bias, \
+                       WhhT, gates, h, c, h_init, c_init, store_gates)
+    switch (P) {
+        case 0: KVAE_R128F(0); break;
+        case 1: KVAE_R128F(1); break;
+        case 2: KVAE_R128F(2); break;
+        case 3: KVAE_R128F(3); break;
+        case 4: KVAE_R128F(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_R128F
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const float* gates,
+                    const float* c, const float* c_init, const float* g_h, const float* Whh,
+                    float* dG, float* dx, float* partial, hipStream_t stream) {
+    const dim3 grid((B + 15) / 16);
+#define KVAE_R128B(P_)                                                                    \
+    hipLaunchKernelGGL(KVAE_BWD_KERNEL<P_>, grid, dim3(256), 0, stream, T, B, x, Wih, gates, \
+                       c, c_init, g_h, Whh, dG, dx, partial)
+    switch (P) {
+        case 0: KVAE_R128B(0); break;
+        case 1: KVAE_R128B(1); break;
+        case 2: KVAE_R128B(2); break;
+        case 3: KVAE_R128B(3); break;
+        case 4: KVAE_R128B(4); break;
+        default: return KVAE_E_UNSUPPORTED;
+    }
+#undef KVAE_R128B
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
 }  // namespace kvae
 
+#ifndef KVAE_LSTM_BF16X3
 using namespace kvae;
 
 // workgroups that are resident at once: one per compute unit (each takes all registers)
@@ -580,9 +822,28 @@ static int resident_workgroups() {
     return n;
 }
 
+// 0: exact fp32 matrix instructions; 1: three bf16 instructions per product (default).
+// KVAE_LSTM_PRECISION=fp32 in the environment selects 0 at the first call.
+static int g_split = -1;
+static int split_products() {
+    if (g_split < 0) {
+        const char* e = getenv("KVAE_LSTM_PRECISION");
+        g_split = (e && (!strcmp(e, "fp32") || !strcmp(e, "exact"))) ? 0 : 1;
+    }
+    return g_split;
+}
+
 extern "C" {
 
 int kvae_lstm128_blocks(int B) { return B < 1 ? 0 : (B + 15) / 16; }
+
+int kvae_lstm128_set_precision(int split) {
+    if (split != 0 && split != 1) return KVAE_E_BADARG;
+    g_split = split;
+    return KVAE_OK;
+}
+
+int kvae_lstm128_get_precision(void) { return split_products(); }
 
 int kvae_lstm128_forward(int T, int B, int P, const void* x, const void* Wih, const void* bias,
                          const void* WhhT, void* gates, void* h, void* c, const void* h_init,
@@ -590,33 +851,20 @@ int kvae_lstm128_forward(int T, int B, int P, const void* x, const void* Wih, co
     if (T < 1 || B < 1 || !WhhT || !h || !c || (h_init == nullptr) != (c_init == nullptr) ||
         (P > 0 && (!x || !Wih || !bias)) || (P == 0 && !gates) || (store_gates && !gates))
         return KVAE_E_BADARG;
+    const bool split = split_products() != 0;
     // A workgroup loads its 256 KB of the recurrent matrix once.  Over a whole sequence that
     // is nothing; a one-step call over very many rows (the masked filter steps the network
     // once per time step) would spend its time on those loads, so it gets one workgroup
     // per compute unit, each working through many tiles.
     if (T < 8 && (B + 15) / 16 > 2 * resident_workgroups())
-        return launch_lstm128_forward_tiles(T, B, P, resident_workgroups(), (const float*)x,
-                                            (const float*)Wih, (const float*)bias,
-                                            (const float*)WhhT, (float*)gates, (float*)h,
-                                            (float*)c, (const float*)h_init,
-                                            (const float*)c_init, store_gates,
-                                            (hipStream_t)stream);
-    const dim3 grid((B + 15) / 16);
-#define KVAE_R128F(P_)                                                                           \
-    hipLaunchKernelGGL(lstm128_resident_forward_kernel<P_>, grid, dim3(256), 0,                  \
-                       (hipStream_t)stream, T, B, (const float*)x, (const float*)Wih,            \
-                       (const float*)bias, (const float*)WhhT, (float*)gates, (float*)h,         \
-                       (float*)c, (const float*)h_init, (const float*)c_init, store_gates)
-    switch (P) {
-        case 0: KVAE_R128F(0); break;
-        case 1: KVAE_R128F(1); break;
-        case 2: KVAE_R128F(2); break;
-        case 3: KVAE_R128F(3); break;
-        case 4: KVAE_R128F(4); break;
-        default: return KVAE_E_UNSUPPORTED;
-    }
-#undef KVAE_R128F
-    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+        return (split ? launch_lstm128_forward_tiles_split : launch_lstm128_forward_tiles)(
+            T, B, P, resident_workgroups(), (const float*)x, (const float*)Wih,
+            (const float*)bias, (const float*)WhhT, (float*)gates, (float*)h, (float*)c,
+            (const float*)h_init, (const float*)c_init, store_gates, (hipStream_t)stream);
+    return (split ? launch_lstm128_forward_split : launch_lstm128_forward_exact)(
+        T, B, P, (const float*)x, (const float*)Wih, (const float*)bias, (const float*)WhhT,
+        (float*)gates, (float*)h, (float*)c, (const float*)h_init, (const float*)c_init,
+        store_gates, (hipStream_t)stream);
 }
 
 int kvae_lstm128_backward(int T, int B, int P, const void* x, const void* Wih, const void* gates,
@@ -625,24 +873,12 @@ int kvae_lstm128_backward(int T, int B, int P, const void* x, const void* Wih, c
     if (T < 1 || B < 1 || !gates || !c || !g_h || !Whh || !dG || !partial ||
         (P > 0 && (!x || !Wih || !dx)))
         return KVAE_E_BADARG;
-    const dim3 grid((B + 15) / 16);
-#define KVAE_R128B(P_)                                                                           \
-    hipLaunchKernelGGL(lstm128_resident_backward_kernel<P_>, grid, dim3(256), 0,                 \
-                       (hipStream_t)stream, T, B, (const float*)x, (const float*)Wih,            \
-                       (const float*)gates, (const float*)c, (const float*)c_init,               \
-                       (const float*)g_h, (const float*)Whh, (float*)dG, (float*)dx,             \
-                       (float*)partial)
-    switch (P) {
-        case 0: KVAE_R128B(0); break;
-        case 1: KVAE_R128B(1); break;
-        case 2: KVAE_R128B(2); break;
-        case 3: KVAE_R128B(3); break;
-        case 4: KVAE_R128B(4); break;
-        default: return KVAE_E_UNSUPPORTED;
-    }
-#undef KVAE_R128B
-    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+    return (split_products() ? launch_lstm128_backward_split : launch_lstm128_backward_exact)(
+        T, B, P, (const float*)x, (const float*)Wih, (const float*)gates, (const float*)c,
+        (const float*)c_init, (const float*)g_h, (const float*)Whh, (float*)dG, (float*)dx,
+        (float*)partial, (hipStream_t)stream);
 }
 
 }  // extern "C"
+#endif   // KVAE_LSTM_BF16X3
 #endif   // KVAE_LSTM_TILE_LOOP
