@@ -500,6 +500,17 @@ int kvae_lstm128_backward(int T, int B, int P, const void *x, const void *Wih, c
                           const void *c, const void *c_init, const void *g_h, const void *Whh,
                           void *dG, void *dx, void *partial, void *stream);
 
+/* Y = X W (+ bias), the two time-batched products of that network's LSTM outside the
+ * recurrences: layer 1's input projection of all steps (K = 128, N = 512, W = weight_ih_l1
+ * transposed, bias = b_ih + b_hh) and the gradient layer 1 hands to layer 0 (K = 512,
+ * N = 128, W = weight_ih_l1 as stored, bias NULL) -- torch.nn.LSTM and its autograd inside
+ * kvae/dynamics_parameter_network.py:46-58.  X (M,K), W (K,N), bias (N) or NULL, Y (M,N),
+ * float32 row-major, 16-byte aligned; any M >= 1.  W stays in registers, X and Y stream
+ * through once; products are formed as in kvae_lstm128_forward with split = 1.  Other
+ * (K,N): KVAE_E_UNSUPPORTED.                                                              */
+int kvae_rowstream_matmul(long M, int K, int N, const void *X, const void *W, const void *bias,
+                          void *Y, void *stream);
+
 /* Softmax head of the dynamics-parameter network, alpha = softmax(h W^T + b):
  * kvae/dynamics_parameter_network.py:57-58 (LSTMModel) and 84-90 (last layer of
  * MLPModel).  float32; h (R,H) with R = T*B rows and H in {32,64,128,256};

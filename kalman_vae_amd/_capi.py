@@ -93,7 +93,7 @@ EXPORTS = (
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
     "kvae_lstm128_blocks", "kvae_lstm128_forward", "kvae_lstm128_backward",
-    "kvae_lstm128_set_precision", "kvae_lstm128_get_precision",
+    "kvae_lstm128_set_precision", "kvae_lstm128_get_precision", "kvae_rowstream_matmul",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
     "kvae_softmax_head_backward_blocks",
     "kvae_cholesky_forward", "kvae_cholesky_backward", "kvae_noise_factors",
@@ -203,6 +203,8 @@ def load():
     lib.kvae_lstm128_set_precision.restype = C.c_int
     lib.kvae_lstm128_get_precision.argtypes = []
     lib.kvae_lstm128_get_precision.restype = C.c_int
+    lib.kvae_rowstream_matmul.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 5
+    lib.kvae_rowstream_matmul.restype = C.c_int
     lib.kvae_lstm128_forward.argtypes = [C.c_int] * 3 + [_vp] * 9 + [C.c_int, _vp]
     lib.kvae_lstm128_forward.restype = C.c_int
     lib.kvae_lstm128_backward.argtypes = [C.c_int] * 3 + [_vp] * 11

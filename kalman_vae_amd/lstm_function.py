@@ -223,6 +223,23 @@ class FusedLSTM2Function(torch.autograd.Function):
         return dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b
 
 
+def _rows_matmul(x2, w, bias, out):
+    """out = x2 @ w (+ bias) for the two tall products around the resident layer kernels:
+    the library's row-streaming kernel (w resident in registers, x2 and out through HBM
+    once) when the product forms agree with the layer kernels', a library GEMM otherwise."""
+    lib = capi.load()
+    if lib.kvae_lstm128_get_precision() == 1 and x2.dtype == torch.float32:
+        w = w.contiguous()
+        capi.check(lib.kvae_rowstream_matmul(
+            x2.shape[0], w.shape[0], w.shape[1], x2.data_ptr(), w.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            capi.current_stream_ptr()))
+        return out
+    if bias is not None:
+        return torch.addmm(bias, x2, w, out=out)
+    return torch.mm(x2, w, out=out)
+
+
 class ResidentLSTM2Function(torch.autograd.Function):
     """Two layers, hidden size 128, layer-0 input dimension <= 4, one launch per layer and
     direction with the layer's recurrent matrix resident in registers
@@ -254,7 +271,7 @@ class ResidentLSTM2Function(torch.autograd.Function):
                 T, B, 0, None, None, None, whh0t.data_ptr(), gates0.data_ptr(), h0.data_ptr(),
                 c0.data_ptr(), None, None, 1, stream))
         # layer 1's input projection of all steps: (T*B,128) x (128,512) + bias
-        torch.addmm(b1, h0.view(T * B, H), wih1t, out=gates1.view(T * B, 4 * H))
+        _rows_matmul(h0.view(T * B, H), wih1t, b1, gates1.view(T * B, 4 * H))
         capi.check(lib.kvae_lstm128_forward(
             T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
             c1.data_ptr(), None, None, 1, stream))
@@ -283,7 +300,8 @@ class ResidentLSTM2Function(torch.autograd.Function):
             whh1.data_ptr(), dG1.data_ptr(), None, part1.data_ptr(), stream))
         d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
         # gradient w.r.t. layer 0's h through layer 1's input product
-        g_h0 = torch.mm(d1, wih1).view(T, B, H)
+        g_h0 = _rows_matmul(d1, wih1, None, torch.empty(T * B, H, dtype=x.dtype,
+                                                        device=x.device)).view(T, B, H)
         if Pk:
             capi.check(lib.kvae_lstm128_backward(
                 T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
@@ -450,7 +468,7 @@ def lstm2_nograd(x, lstm, hidden=None):
         capi.check(lib.kvae_lstm128_forward(
             T, B, P, x.data_ptr(), keep[0].data_ptr(), b0.data_ptr(), whh0t.data_ptr(), None,
             h0.data_ptr(), c0.data_ptr(), init(h_init, 0), init(c_init, 0), 0, stream))
-        gates1 = torch.addmm(b1, h0.view(T * B, H), wih1t)
+        gates1 = _rows_matmul(h0.view(T * B, H), wih1t, b1, new(T * B, 4 * H))
         capi.check(lib.kvae_lstm128_forward(
             T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
             c1.data_ptr(), init(h_init, 1), init(c_init, 1), 0, stream))

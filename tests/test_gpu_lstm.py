@@ -208,3 +208,31 @@ def test_resident_layer_many_tiles_per_workgroup_matches_torch(T, B, P, gates):
         c_prev = c[-2] if T > 1 else ci
         assert rel_err(f_g * c_prev + i_g * g_g, c[-1]) < 1e-5
         assert rel_err(o_g * torch.tanh(c[-1]), h[-1]) < 1e-5
+
+
+@pytest.mark.parametrize("M,K,N,with_bias", [(16 * 300, 128, 512, True), (16 * 300 + 7, 512, 128, False),
+                                              (5, 128, 512, False), (81920, 512, 128, True),
+                                              (1, 512, 128, False), (16 * 257 + 15, 128, 512, True)])
+def test_rowstream_matmul_matches_float64(M, K, N, with_bias):
+    """kvae_rowstream_matmul (the matrix resident in registers, rows streamed in 16-row tiles,
+    split-bf16 products) against a float64 product: full and ragged last tiles, fewer tiles
+    than workgroups, more tiles than workgroups."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(M + K)
+    dev = torch.device("cuda:0")
+    X = torch.randn(M, K, device=dev)
+    W = torch.randn(K, N, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev) if with_bias else None
+    Y = torch.full((M, N), float("nan"), device=dev)
+    rc = lib.kvae_rowstream_matmul(M, K, N, X.data_ptr(), W.data_ptr(),
+                                   b.data_ptr() if with_bias else None, Y.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = X.double() @ W.double() + (b.double() if with_bias else 0.0)
+    assert rel_err(Y, ref) < 1e-5
+    # every entry, not only the largest: the error of one entry against the size of its terms
+    scale = X.double().abs() @ W.double().abs() + 1.0
+    assert float(((Y.double() - ref).abs() / scale).max()) < 1e-5
+    assert lib.kvae_rowstream_matmul(M, 64, 64, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(),
+                                     None) == -2   # KVAE_E_UNSUPPORTED
