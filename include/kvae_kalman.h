@@ -486,7 +486,7 @@ int kvae_lstm2_backward(int T, int B, int P, const void *g_h1, const void *x, co
 int kvae_lstm128_blocks(int B);
 /* How the two kernels above form their matrix products.  split = 1 (the default): every
  * fp32 product a*b is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo on the bf16 matrix instruction with
- * fp32 accumulation (x = x_hi + x_lo, both bf16): about 1e-5 relative per product, 1e-6 on
+ * fp32 accumulation (x = x_hi + x_lo, both bf16): about 1e-5 relative per product (5e-5 at worst), 1e-6 on
  * a 128-term gate sum, a fifth of the matrix-instruction time.  split = 0: the fp32 matrix
  * instruction, exact fp32 products.  KVAE_LSTM_PRECISION=fp32 in the environment selects 0
  * at the first call.  Process-wide; no counterpart in the reference (torch.nn.LSTM's
@@ -510,6 +510,19 @@ int kvae_lstm128_backward(int T, int B, int P, const void *x, const void *Wih, c
  * (K,N): KVAE_E_UNSUPPORTED.                                                              */
 int kvae_rowstream_matmul(long M, int K, int N, const void *X, const void *W, const void *bias,
                           void *Y, void *stream);
+
+/* Weight gradient of one such LSTM layer: dW = dG^T H with dG (R,512) the gate gradients
+ * kvae_lstm128_backward wrote and H (R,128) the layer's input or its own h one step earlier
+ * (autograd of torch.nn.LSTM, kvae/dynamics_parameter_network.py:46-58); R = T*B.
+ * Row m of dG is paired with row m - shift of H (rows m < shift contribute nothing):
+ * shift = 0 for weight_ih, shift = B for weight_hh.  The rows are cut into
+ * kvae_lstm128_wgrad_slabs(R) slabs; slab s writes its (512,128) float32 result at
+ * partial + s * partial_stride (elements, >= 65536), and the sum over s (kvae_column_sum)
+ * is the gradient: fixed summation order, no atomics.  dG, H 16-byte aligned.  Products are
+ * formed as in kvae_lstm128_forward with split = 1.                                       */
+int kvae_lstm128_wgrad_slabs(long R);
+int kvae_lstm128_wgrad(long R, const void *dG, const void *H, long shift, void *partial,
+                       long partial_stride, void *stream);
 
 /* Softmax head of the dynamics-parameter network, alpha = softmax(h W^T + b):
  * kvae/dynamics_parameter_network.py:57-58 (LSTMModel) and 84-90 (last layer of

@@ -94,6 +94,7 @@ EXPORTS = (
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
     "kvae_lstm128_blocks", "kvae_lstm128_forward", "kvae_lstm128_backward",
     "kvae_lstm128_set_precision", "kvae_lstm128_get_precision", "kvae_rowstream_matmul",
+    "kvae_lstm128_wgrad_slabs", "kvae_lstm128_wgrad",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
     "kvae_softmax_head_backward_blocks",
     "kvae_cholesky_forward", "kvae_cholesky_backward", "kvae_noise_factors",
@@ -205,6 +206,10 @@ def load():
     lib.kvae_lstm128_get_precision.restype = C.c_int
     lib.kvae_rowstream_matmul.argtypes = [C.c_long, C.c_int, C.c_int] + [_vp] * 5
     lib.kvae_rowstream_matmul.restype = C.c_int
+    lib.kvae_lstm128_wgrad_slabs.argtypes = [C.c_long]
+    lib.kvae_lstm128_wgrad_slabs.restype = C.c_int
+    lib.kvae_lstm128_wgrad.argtypes = [C.c_long, _vp, _vp, C.c_long, _vp, C.c_long, _vp]
+    lib.kvae_lstm128_wgrad.restype = C.c_int
     lib.kvae_lstm128_forward.argtypes = [C.c_int] * 3 + [_vp] * 9 + [C.c_int, _vp]
     lib.kvae_lstm128_forward.restype = C.c_int
     lib.kvae_lstm128_backward.argtypes = [C.c_int] * 3 + [_vp] * 11

@@ -51,9 +51,9 @@ struct GateRows {                  // one lane's 4 rows x 2 units of the four ga
 // (16x16x4, 32 cycles) is replaced by three bf16 ones (16x16x32, 16 cycles each, eight
 // times the depth): with x = x_hi + x_lo, both bf16, x_lo = bf16(x - x_hi),
 //     a b  ~  a_hi b_hi + a_lo b_hi + a_hi b_lo          (accumulated in fp32)
-// drops a_lo b_lo and the two representation residuals, each below 2^-17 |a b|: a product
-// is good to about 1e-5 relative (fp32: 6e-8), a 128-term gate sum to about 1e-6 of the sum
-// of its terms' magnitudes.  Operands use the same registers as the fp32 form (a hi and a
+// drops a_lo b_lo and the two representation residuals, each below 2^-16 |a b|: a product
+// is good to about 1e-5 relative (5e-5 at worst; fp32: 6e-8), a 128-term gate sum to about
+// 1e-6 of the sum of its terms' magnitudes.  Operands use the same registers as the fp32 form (a hi and a
 // lo bf16 per fp32 value); a step needs 96 matrix instructions of 16 cycles instead of 256
 // of 32.  The kernels of this build carry `split` in their names.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

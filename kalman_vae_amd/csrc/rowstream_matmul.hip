@@ -11,7 +11,7 @@
 // through 16-row tiles of X: global -> registers -> split -> LDS (double buffered, the next
 // tile's loads in flight while this tile's matrix instructions run) -> A operands.  Every
 // fp32 product is a_hi b_hi + a_lo b_hi + a_hi b_lo with fp32 accumulation (about 1e-5
-// relative per product; see lstm_resident.hip).  Wavefront w owns N/4 adjacent output
+// relative per product, 5e-5 at worst; see lstm_resident.hip).  Wavefront w owns N/4 adjacent output
 // columns, lane (cc, s) of it rows 4s..4s+3 and the N/64 adjacent columns from
 // w N/4 + cc N/64, so Y is written in 32-byte (N = 512) or 8-byte (N = 128) pieces.
 #include <hip/hip_runtime.h>

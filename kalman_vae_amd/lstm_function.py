@@ -320,7 +320,17 @@ class ResidentLSTM2Function(torch.autograd.Function):
             torch.mm(d0, wih0, out=dx.view(T * B, P))
             dw_ih0 = _splitk_tn(d0, x.view(T * B, P))
         zero = lambda w: torch.zeros_like(w)
-        if T > 1:
+        if T > 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1:
+            # dG0^T h0_{t-1}, dG1^T h0_t, dG1^T h1_{t-1}: one launch each into one buffer of
+            # per-slab results, one launch sums the slabs of all three
+            R, E = T * B, 4 * H * H
+            S = lib.kvae_lstm128_wgrad_slabs(R)
+            slabs = torch.empty(S, 3 * E, dtype=x.dtype, device=x.device)
+            for i, (dg, hh, shift) in enumerate(((d0, h0, B), (d1, h0, 0), (d1, h1, B))):
+                capi.check(lib.kvae_lstm128_wgrad(R, dg.data_ptr(), hh.data_ptr(), shift,
+                                                  slabs[:, i * E:].data_ptr(), 3 * E, stream))
+            dw_hh0, dw_ih1, dw_hh1 = capi.column_sum(slabs).view(3, 4 * H, H).unbind(0)
+        elif T > 1:
             dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
                 (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),
                 (d1[B:], h1[:-1].reshape(-1, H))])

@@ -236,3 +236,38 @@ def test_rowstream_matmul_matches_float64(M, K, N, with_bias):
     assert float(((Y.double() - ref).abs() / scale).max()) < 1e-5
     assert lib.kvae_rowstream_matmul(M, 64, 64, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(),
                                      None) == -2   # KVAE_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("T,B", [(20, 256), (3, 37), (2, 1), (7, 1000), (20, 4096)])
+def test_wgrad_matches_float64(T, B):
+    """kvae_lstm128_wgrad (dG^T H over T*B rows in slabs, split-bf16 products) against float64,
+    with and without the one-step row offset; ragged slabs and fewer rows than one step."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(T * 1000 + B)
+    dev = torch.device("cuda:0")
+    H, R = 128, T * B
+    E = 4 * H * H
+    dG = torch.randn(R, 4 * H, device=dev)
+    h0, h1 = torch.tanh(torch.randn(R, H, device=dev)), torch.tanh(torch.randn(R, H, device=dev))
+    S = lib.kvae_lstm128_wgrad_slabs(R)
+    assert 1 <= S <= 64
+    slabs = torch.full((S, 3 * E), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for i, (hh, shift) in enumerate(((h0, B), (h0, 0), (h1, B))):
+        assert lib.kvae_lstm128_wgrad(R, dG.data_ptr(), hh.data_ptr(), shift,
+                                      slabs[:, i * E:].data_ptr(), 3 * E, st) == 0
+    got = capi.column_sum(slabs).view(3, 4 * H, H)
+    d64, a64, b64 = dG.double(), h0.double(), h1.double()
+    ref = [d64[B:].t() @ a64[:R - B], d64.t() @ a64, d64[B:].t() @ b64[:R - B]]
+    mag = [d64[B:].abs().t() @ a64[:R - B].abs(), d64.abs().t() @ a64.abs(),
+           d64[B:].abs().t() @ b64[:R - B].abs()]
+    for i in range(3):
+        # each entry against the size of its terms (the sums themselves cancel to ~sqrt(R)):
+        # a split product is good to ~1e-5 of its magnitude (5e-5 at worst), a sum of N of
+        # them to ~1e-5/sqrt(N)
+        err = float(((got[i].double() - ref[i]).abs() / (mag[i] + 1e-30)).max()) if R > B else \
+            float(got[i].abs().max())
+        assert err < (5e-5 if R < 4096 else 2e-6), (i, err)
+    assert lib.kvae_lstm128_wgrad(R, dG.data_ptr(), h0.data_ptr(), 0, slabs.data_ptr(), E - 1,
+                                  st) != 0
