@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkvae_kalman.so")
+# KVAE_LIB_PATH: another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("KVAE_LIB_PATH") or os.path.join(_HERE, "csrc", "libkvae_kalman.so")
 
 KVAE_F32, KVAE_F64 = 0, 1
 OP_FILTER_BWD, OP_SMOOTH_BWD, OP_ELBO_BWD, OP_LOSS_FWD, OP_LOSS_BWD = 1, 2, 3, 4, 5

@@ -13,13 +13,15 @@ namespace kvae {
 constexpr int WAVE = 64;
 
 // (n, p, K) combinations the small-state kernels (one or four lanes per sequence) are
-// compiled for
+// compiled for (an experiment build may define a shorter list on the command line)
+#ifndef KVAE_DIM_LIST
 #define KVAE_DIM_LIST(X) \
     X(4, 2, 3)           \
     X(2, 1, 2)           \
     X(3, 2, 2)           \
     X(4, 2, 8)           \
     X(8, 4, 4)
+#endif
 
 // Lane exchange inside a row of 16 lanes by a DPP control word (no LDS crossbar).
 template <int CTRL>

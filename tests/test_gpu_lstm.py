@@ -10,16 +10,32 @@ from golden_util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("persistent", ["resident", 16, 32, 0])
+@pytest.fixture
+def exact_products():
+    """The resident kernels with the exact fp32 matrix instruction for the test's duration."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    assert lib.kvae_lstm128_set_precision(0) == 0 and lib.kvae_lstm128_get_precision() == 0
+    yield
+    assert lib.kvae_lstm128_set_precision(1) == 0
+
+
+@pytest.mark.parametrize("persistent", ["resident", "resident-exact", 16, 32, 0])
 @pytest.mark.parametrize("T,B,p,H,L", [(20, 70, 2, 128, 2), (5, 33, 3, 32, 1), (7, 64, 2, 64, 3),
                                        (1, 40, 2, 128, 2), (3, 1, 16, 128, 2), (9, 32, 4, 128, 2),
                                        (4, 200, 1, 128, 2)])
-def test_fused_lstm_matches_torch(T, B, p, H, L, persistent, monkeypatch):
+def test_fused_lstm_matches_torch(T, B, p, H, L, persistent, monkeypatch, request):
     import kalman_vae_amd.lstm_function as lf
     from kalman_vae_amd.lstm_function import fused_lstm
     # persistent: tile rows of the one-launch two-layer kernels (both forms are
     # forced in turn; the library picks by batch size otherwise), 0 = per-step kernels
-    # "resident": one launch per layer, recurrent matrix in registers (the default)
+    # "resident": one launch per layer, recurrent matrix in registers (the default: products
+    # as three bf16 matrix instructions, with the row-streaming and weight-gradient kernels
+    # around them); "resident-exact": the same with the fp32 matrix instruction and library
+    # GEMMs around them
+    if persistent == "resident-exact":
+        request.getfixturevalue("exact_products")
+        persistent = "resident"
     monkeypatch.setattr(lf, "PERSISTENT", bool(persistent))
     monkeypatch.setattr(lf, "RESIDENT", persistent == "resident")
     if persistent and persistent != "resident":

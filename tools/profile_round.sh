@@ -4,6 +4,7 @@ export TMPDIR=/tmp
 R=$PWD
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 > gpurun_out/r02/bench_prof.json 2> gpurun_out/r02/bench_prof.err
 echo trace done
+python3 tools/summarize_rocprof.py $(find gpurun_out/r02/prof -name "*kernel_stats.csv" | head -1) 25 > gpurun_out/r02/bench_c2_kernel_stats.md
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r02/pmc_f_loss -o p --output-format csv -- python3 tools/time_loss_kernels.py 4096 > gpurun_out/r02/pmc_f_loss.log 2>&1
 echo pmc1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r02/pmc_w_loss -o p --output-format csv -- python3 tools/time_loss_kernels.py 4096 > gpurun_out/r02/pmc_w_loss.log 2>&1
@@ -12,4 +13,6 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r02/pmc_f_lstm -
 echo pmc3
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r02/pmc_w_lstm -o p --output-format csv -- python3 tools/run_lstm128_once.py 4096 > gpurun_out/r02/pmc_w_lstm.log 2>&1
 echo pmc4
-find gpurun_out/r02 -name "*.csv" | head -30
+python3 tools/pmc_traffic.py $(find gpurun_out/r02/pmc_f_lstm gpurun_out/r02/pmc_w_lstm -name "*counter_collection.csv") > gpurun_out/r02/pmc_lstm.json
+python3 tools/pmc_traffic.py $(find gpurun_out/r02/pmc_f_loss gpurun_out/r02/pmc_w_loss -name "*counter_collection.csv") > gpurun_out/r02/pmc_loss.json
+cat gpurun_out/r02/pmc_lstm.json

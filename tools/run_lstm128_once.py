@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Launch each register-resident LSTM layer kernel a few times (for rocprofv3 counter runs)."""
+"""Launch each kernel of the LSTM weight network a few times (register-resident layer kernels,
+the row-streaming products, the weight-gradient product) for rocprofv3 counter runs."""
 import os
 import sys
 
@@ -36,4 +37,14 @@ for _ in range(3):
     lib.kvae_lstm128_backward(T, B, 0, None, None, gates.data_ptr(), c.data_ptr(), None,
                               g_h.data_ptr(), whh.data_ptr(), dG.data_ptr(), None, part.data_ptr(),
                               st)
+    R = T * B
+    wih1 = 0.08 * new(4 * H, H)
+    wih1t = wih1.t().contiguous()
+    gh0 = new(R, H)
+    S = lib.kvae_lstm128_wgrad_slabs(R)
+    slabs = new(S, 4 * H * H)
+    lib.kvae_rowstream_matmul(R, H, 4 * H, h.data_ptr(), wih1t.data_ptr(), bias.data_ptr(),
+                              gx2.data_ptr(), st)
+    lib.kvae_rowstream_matmul(R, 4 * H, H, dG.data_ptr(), wih1.data_ptr(), None, gh0.data_ptr(), st)
+    lib.kvae_lstm128_wgrad(R, dG.data_ptr(), h.data_ptr(), B, slabs.data_ptr(), 4 * H * H, st)
 torch.cuda.synchronize()
