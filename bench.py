@@ -170,11 +170,12 @@ def time_lstm_kernels(ssm, a, iters=20):
                  "lstm_layer0_backward": f"lstm128_{fam}_backward_kernel<{P}>"}
     flops = 2.0 * T * B * 4 * H * H     # the recurrent product of one layer
     # compulsory HBM bytes of a launch: activated gates, h, c written (forward) / read with
-    # the upstream gradient and c_{t-1}, gate gradients written (backward)
+    # the upstream gradient (c_{t-1} is carried from the previous step), gate gradients
+    # written (backward)
     by = {"lstm_layer0_forward": 4.0 * T * B * (6 * H + P),
           "lstm_layer1_forward": 4.0 * T * B * (6 * H + 4 * H),
-          "lstm_layer1_backward": 4.0 * T * B * (7 * H + 4 * H),
-          "lstm_layer0_backward": 4.0 * T * B * (7 * H + 4 * H + 2 * P)}
+          "lstm_layer1_backward": 4.0 * T * B * (6 * H + 4 * H),
+          "lstm_layer0_backward": 4.0 * T * B * (6 * H + 4 * H + 2 * P)}
     if split:
         # the products around the recurrences, same arithmetic, each its own launch
         R = T * B

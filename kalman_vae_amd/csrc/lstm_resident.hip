@@ -543,12 +543,16 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             }
         }
     }
+    // c_t of step t is c_{t-1} of step t+1, which the previous iteration already holds: only
+    // the first step (t = T-1) reads it from memory
     auto load_rows = [&](int t, CellRows& in) {
         const float2 z = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 4 * s + i;
-            in.ig[i] = in.fg[i] = in.gg[i] = in.og[i] = in.cc[i] = in.cp[i] = in.gh[i] = z;
+            const float2 c_here = in.cp[i];
+            in.ig[i] = in.fg[i] = in.gg[i] = in.og[i] = in.cp[i] = in.gh[i] = z;
+            in.cc[i] = t == T - 1 ? z : c_here;
             if (FULL || row < B) {
                 const float* gr = gates + t * BG + (long)row * RG4 + ub;
                 in.ig[i] = load_streaming(gr);
@@ -556,7 +560,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                 in.gg[i] = load_streaming(gr + 2 * RH);
                 in.og[i] = load_streaming(gr + 3 * RH);
                 const long o = (long)row * RH + ub;
-                in.cc[i] = load_streaming(cg + t * BH + o);
+                if (t == T - 1) in.cc[i] = load_streaming(cg + t * BH + o);
                 if (t > 0) {
                     in.cp[i] = load_streaming(cg + (t - 1) * BH + o);
                 } else if (c_init) {
@@ -568,6 +572,8 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     };
 
     CellRows in;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in.cp[i] = make_float2(0.f, 0.f);
     load_rows(T - 1, in);
     for (int t = T - 1; t >= 0; --t) {
 #ifndef KVAE_LSTM_BF16X3
