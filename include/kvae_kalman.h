@@ -570,6 +570,10 @@ int kvae_noise_factors(int n, int p, int dtype, const void *Lq, const void *Lr, 
  *   kvae_vector_sum_scratch_elems(batch, n) elements of the same dtype (may be 0).
  */
 int kvae_column_sum(long rows, int cols, int dtype, const void *in, void *out, void *stream);
+/* The column sums of up to four matrices of one dtype in ONE launch: rows[i], cols[i], in[i],
+ * out[i] as in kvae_column_sum (host arrays of `parts` entries, read before the call returns). */
+int kvae_column_sum_many(int parts, const long *rows, const int *cols, int dtype,
+                         const void *const *in, void *const *out, void *stream);
 long kvae_vector_sum_scratch_elems(int batch, long n);
 int kvae_vector_sum(int batch, long n, int dtype, const void *in, void *scratch, void *out,
                     void *stream);

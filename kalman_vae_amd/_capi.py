@@ -100,7 +100,7 @@ EXPORTS = (
     "kvae_softmax_head_backward_blocks",
     "kvae_cholesky_forward", "kvae_cholesky_backward", "kvae_noise_factors",
     "kvae_graph_count_memset_nodes", "kvae_graph_count_kernel_nodes",
-    "kvae_column_sum", "kvae_vector_sum", "kvae_vector_sum_scratch_elems",
+    "kvae_column_sum", "kvae_column_sum_many", "kvae_vector_sum", "kvae_vector_sum_scratch_elems",
     "kvae_weighted_terms", "kvae_weighted_terms_scratch_elems",
 )
 
@@ -261,6 +261,9 @@ def load():
     lib.kvae_weighted_terms_scratch_elems.restype = C.c_long
     lib.kvae_column_sum.argtypes = [C.c_long, C.c_int, C.c_int, _vp, _vp, _vp]
     lib.kvae_column_sum.restype = C.c_int
+    lib.kvae_column_sum_many.argtypes = [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]
+    lib.kvae_column_sum_many.restype = C.c_int
     lib.kvae_vector_sum.argtypes = [C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]
     lib.kvae_vector_sum.restype = C.c_int
     lib.kvae_vector_sum_scratch_elems.argtypes = [C.c_int, C.c_long]
@@ -276,6 +279,20 @@ def column_sum(x):
     check(load().kvae_column_sum(x.shape[0], x.shape[1], dtype_code(x.dtype), ptr(x),
                                  out.data_ptr(), current_stream_ptr()))
     return out
+
+
+def column_sum_many(xs):
+    """Column sums of up to four contiguous 2-D GPU tensors of one dtype in one launch."""
+    require_gpu(*xs)
+    n = len(xs)
+    outs = [torch.empty(x.shape[1], dtype=x.dtype, device=x.device) for x in xs]
+    rows = (C.c_long * n)(*[x.shape[0] for x in xs])
+    cols = (C.c_int * n)(*[x.shape[1] for x in xs])
+    ins = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    ous = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(load().kvae_column_sum_many(n, rows, cols, dtype_code(xs[0].dtype), ins, ous,
+                                      current_stream_ptr()))
+    return outs
 
 
 def column_sum_tall(x):

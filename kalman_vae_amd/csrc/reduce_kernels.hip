@@ -40,6 +40,71 @@ column_sum_kernel(long rows, int cols, const T* __restrict__ in, T* __restrict__
     }
 }
 
+// The same sums for up to four matrices in ONE launch (each launch of a dependent chain
+// costs ~5 us whatever its size): workgroup b belongs to the matrix whose block range
+// contains b.
+constexpr int COLSUM_MAX_PARTS = 4;
+template <typename T>
+struct ColumnSumParts {
+    long rows[COLSUM_MAX_PARTS];
+    int cols[COLSUM_MAX_PARTS];
+    int first_block[COLSUM_MAX_PARTS + 1];
+    const T* in[COLSUM_MAX_PARTS];
+    T* out[COLSUM_MAX_PARTS];
+};
+template <typename T>
+__global__ void __launch_bounds__(64 * COLSUM_WAVES)
+column_sum_many_kernel(int parts, ColumnSumParts<T> p) {
+    __shared__ T sm[COLSUM_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < COLSUM_MAX_PARTS; ++i)
+        if (i < parts && (int)blockIdx.x >= p.first_block[i]) k = i;
+    const long rows = p.rows[k];
+    const int cols = p.cols[k];
+    const T* __restrict__ in = p.in[k];
+    const int c = ((int)blockIdx.x - p.first_block[k]) * 64 + lane;
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    if (c < cols) {
+        for (long r = wave; r < rows; r += 4 * COLSUM_WAVES) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long rr = r + (long)u * COLSUM_WAVES;
+                if (rr < rows) acc[u] += in[rr * cols + c];
+            }
+        }
+    }
+    sm[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        T s = T(0);
+#pragma unroll
+        for (int w = 0; w < COLSUM_WAVES; ++w) s += sm[w][lane];
+        p.out[k][c] = s;
+    }
+}
+
+template <typename T>
+int launch_column_sum_many(int parts, const long* rows, const int* cols, const void* const* in,
+                           void* const* out, hipStream_t s) {
+    ColumnSumParts<T> p = {};
+    int blocks = 0;
+    for (int i = 0; i < parts; ++i) {
+        if (rows[i] < 0 || cols[i] < 1 || !in[i] || !out[i]) return KVAE_E_BADARG;
+        p.rows[i] = rows[i];
+        p.cols[i] = cols[i];
+        p.first_block[i] = blocks;
+        p.in[i] = (const T*)in[i];
+        p.out[i] = (T*)out[i];
+        blocks += (cols[i] + 63) / 64;
+    }
+    p.first_block[parts] = blocks;
+    hipLaunchKernelGGL((column_sum_many_kernel<T>), dim3(blocks), dim3(64 * COLSUM_WAVES), 0, s,
+                       parts, p);
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
 constexpr int VECSUM_BLOCK = 1024;
 constexpr long VECSUM_CHUNK = 8192;       // elements per workgroup of the first level
 constexpr int VECSUM_MAX_CHUNKS = 1024;
@@ -153,6 +218,17 @@ int kvae_column_sum(long rows, int cols, int dtype, const void* in, void* out, v
     else
         return KVAE_E_BADARG;
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+int kvae_column_sum_many(int parts, const long* rows, const int* cols, int dtype,
+                         const void* const* in, void* const* out, void* stream) {
+    if (parts < 1 || parts > kvae::COLSUM_MAX_PARTS || !rows || !cols || !in || !out)
+        return KVAE_E_BADARG;
+    if (dtype == KVAE_F32)
+        return kvae::launch_column_sum_many<float>(parts, rows, cols, in, out, (hipStream_t)stream);
+    if (dtype == KVAE_F64)
+        return kvae::launch_column_sum_many<double>(parts, rows, cols, in, out, (hipStream_t)stream);
+    return KVAE_E_BADARG;
 }
 
 long kvae_vector_sum_scratch_elems(int batch, long n) {

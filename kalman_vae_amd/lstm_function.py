@@ -311,7 +311,21 @@ class ResidentLSTM2Function(torch.autograd.Function):
             capi.check(lib.kvae_lstm128_backward(
                 T, B, 0, None, None, gates0.data_ptr(), c0.data_ptr(), None, g_h0.data_ptr(),
                 whh0.data_ptr(), dG0.data_ptr(), None, part0.data_ptr(), stream))
-        s1, s0 = capi.column_sum(part1), capi.column_sum(part0)
+        split = T > 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1
+        slabs = None
+        if split:
+            # dG0^T h0_{t-1}, dG1^T h0_t, dG1^T h1_{t-1}: one launch each into one buffer of
+            # per-slab results; ONE launch then sums the slabs of all three and the two
+            # layers' per-workgroup bias / input-weight partial sums
+            R, E = T * B, 4 * H * H
+            S = lib.kvae_lstm128_wgrad_slabs(R)
+            slabs = torch.empty(S, 3 * E, dtype=x.dtype, device=x.device)
+            for i, (dg, hh, shift) in enumerate(((d0, h0, B), (d1, h0, 0), (d1, h1, B))):
+                capi.check(lib.kvae_lstm128_wgrad(R, dg.data_ptr(), hh.data_ptr(), shift,
+                                                  slabs[:, i * E:].data_ptr(), 3 * E, stream))
+            s1, s0, sw = capi.column_sum_many([part1, part0, slabs])
+        else:
+            s1, s0 = capi.column_sum(part1), capi.column_sum(part0)
         db1, db1b = s1[:4 * H], s1[4 * H:]
         db0, db0b = s0[:4 * H], s0[4 * H:8 * H]
         if Pk:
@@ -320,16 +334,8 @@ class ResidentLSTM2Function(torch.autograd.Function):
             torch.mm(d0, wih0, out=dx.view(T * B, P))
             dw_ih0 = _splitk_tn(d0, x.view(T * B, P))
         zero = lambda w: torch.zeros_like(w)
-        if T > 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1:
-            # dG0^T h0_{t-1}, dG1^T h0_t, dG1^T h1_{t-1}: one launch each into one buffer of
-            # per-slab results, one launch sums the slabs of all three
-            R, E = T * B, 4 * H * H
-            S = lib.kvae_lstm128_wgrad_slabs(R)
-            slabs = torch.empty(S, 3 * E, dtype=x.dtype, device=x.device)
-            for i, (dg, hh, shift) in enumerate(((d0, h0, B), (d1, h0, 0), (d1, h1, B))):
-                capi.check(lib.kvae_lstm128_wgrad(R, dg.data_ptr(), hh.data_ptr(), shift,
-                                                  slabs[:, i * E:].data_ptr(), 3 * E, stream))
-            dw_hh0, dw_ih1, dw_hh1 = capi.column_sum(slabs).view(3, 4 * H, H).unbind(0)
+        if split:
+            dw_hh0, dw_ih1, dw_hh1 = sw.view(3, 4 * H, H).unbind(0)
         elif T > 1:
             dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
                 (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),

@@ -287,3 +287,20 @@ def test_wgrad_matches_float64(T, B):
         assert err < (5e-5 if R < 4096 else 2e-6), (i, err)
     assert lib.kvae_lstm128_wgrad(R, dG.data_ptr(), h0.data_ptr(), 0, slabs.data_ptr(), E - 1,
                                   st) != 0
+
+
+def test_column_sum_many_equals_separate_sums():
+    """kvae_column_sum_many: several matrices in one launch give the bits of kvae_column_sum
+    on each (ragged column counts, one matrix with a single row, float64 too)."""
+    from kalman_vae_amd import _capi as capi
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for dt in (torch.float32, torch.float64):
+        xs = [torch.randn(256, 1024, dtype=dt, device=dev), torch.randn(37, 2051, dtype=dt, device=dev),
+              torch.randn(1, 5, dtype=dt, device=dev), torch.randn(64, 70000, dtype=dt, device=dev)]
+        got = capi.column_sum_many(xs)
+        for x, g in zip(xs, got):
+            assert torch.equal(g, capi.column_sum(x))
+    assert len(capi.column_sum_many(xs[:1])) == 1
+    with pytest.raises(RuntimeError):
+        capi.column_sum_many(xs + xs[:1])
