@@ -144,6 +144,11 @@ def time_lstm_kernels(ssm, a, iters=20):
     dG, dx = new(T, B, 4 * H), new(T, B, P)
     gh = torch.randn(T, B, H, dtype=x.dtype, device=dev) * 1e-3
     part = new(lib.kvae_lstm128_blocks(B), 4 * H * (2 + P))
+    KH = 3
+    al = torch.softmax(torch.randn(T, B, KH, dtype=x.dtype, device=dev), -1)
+    gal = torch.randn(T, B, KH, dtype=x.dtype, device=dev) * 1e-3
+    wh = torch.randn(KH, H, dtype=x.dtype, device=dev) * 0.1
+    hpart = new(lib.kvae_lstm128_blocks(B), KH * (H + 1))
     wih0, whh0, whh1 = w("weight_ih_l0"), w("weight_hh_l0"), w("weight_hh_l1")
     whh0t, whh1t = whh0.t().contiguous(), whh1.t().contiguous()
     b0 = (w("bias_ih_l0") + w("bias_hh_l0")).contiguous()
@@ -155,9 +160,11 @@ def time_lstm_kernels(ssm, a, iters=20):
         "lstm_layer1_forward": lambda: capi.check(lib.kvae_lstm128_forward(
             T, B, 0, None, None, None, whh1t.data_ptr(), gx.data_ptr(), h.data_ptr(), c.data_ptr(),
             None, None, 1, st)),
-        "lstm_layer1_backward": lambda: capi.check(lib.kvae_lstm128_backward(
-            T, B, 0, None, None, gates.data_ptr(), c.data_ptr(), None, gh.data_ptr(),
-            whh1.data_ptr(), dG.data_ptr(), None, part.data_ptr(), st)),
+        # the upper layer's backward with the softmax head's adjoint in the kernel, as the
+        # step runs it
+        "lstm_layer1_backward": lambda: capi.check(lib.kvae_lstm128_backward_head(
+            T, B, KH, gates.data_ptr(), c.data_ptr(), None, al.data_ptr(), gal.data_ptr(),
+            wh.data_ptr(), whh1.data_ptr(), dG.data_ptr(), part.data_ptr(), hpart.data_ptr(), st)),
         "lstm_layer0_backward": lambda: capi.check(lib.kvae_lstm128_backward(
             T, B, P, x.data_ptr(), wih0.data_ptr(), gates.data_ptr(), c.data_ptr(), None,
             gh.data_ptr(), whh0.data_ptr(), dG.data_ptr(), dx.data_ptr(), part.data_ptr(), st)),
@@ -166,15 +173,15 @@ def time_lstm_kernels(ssm, a, iters=20):
     fam = "split" if split else "resident"
     kernel_of = {"lstm_layer0_forward": f"lstm128_{fam}_forward_kernel<{P}>",
                  "lstm_layer1_forward": f"lstm128_{fam}_forward_kernel<0>",
-                 "lstm_layer1_backward": f"lstm128_{fam}_backward_kernel<0>",
-                 "lstm_layer0_backward": f"lstm128_{fam}_backward_kernel<{P}>"}
+                 "lstm_layer1_backward": f"lstm128_{fam}_backward_kernel<0, {KH}>",
+                 "lstm_layer0_backward": f"lstm128_{fam}_backward_kernel<{P}, 0>"}
     flops = 2.0 * T * B * 4 * H * H     # the recurrent product of one layer
     # compulsory HBM bytes of a launch: activated gates, h, c written (forward) / read with
     # the upstream gradient (c_{t-1} is carried from the previous step), gate gradients
     # written (backward)
     by = {"lstm_layer0_forward": 4.0 * T * B * (6 * H + P),
           "lstm_layer1_forward": 4.0 * T * B * (6 * H + 4 * H),
-          "lstm_layer1_backward": 4.0 * T * B * (6 * H + 4 * H),
+          "lstm_layer1_backward": 4.0 * T * B * (5 * H + 4 * H + 2 * KH),
           "lstm_layer0_backward": 4.0 * T * B * (6 * H + 4 * H + 2 * P)}
     if split:
         # the products around the recurrences, same arithmetic, each its own launch

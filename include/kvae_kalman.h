@@ -500,6 +500,19 @@ int kvae_lstm128_backward(int T, int B, int P, const void *x, const void *Wih, c
                           const void *c, const void *c_init, const void *g_h, const void *Whh,
                           void *dG, void *dx, void *partial, void *stream);
 
+/* kvae_lstm128_backward for the upper layer (P = 0) with the network's softmax head
+ * alpha = softmax(h W^T + b), W (K,H), K in 2..4, on top of it
+ * (kvae/dynamics_parameter_network.py:57-58): instead of reading the gradient w.r.t. h the
+ * kernel forms it from alpha (T,B,K) and g_alpha (T,B,K), the gradient w.r.t. alpha, and also
+ * sums the head's parameter gradients: head_partial (kvae_lstm128_blocks(B), K*(H+1)) whose
+ * column sum over the first axis is [ dW (K,H) | db (K) ] (the layout of
+ * kvae_softmax_head_backward).  Everything else as kvae_lstm128_backward.  Other K:
+ * KVAE_E_UNSUPPORTED (use kvae_softmax_head_backward, then kvae_lstm128_backward).      */
+int kvae_lstm128_backward_head(int T, int B, int K, const void *gates, const void *c,
+                               const void *c_init, const void *alpha, const void *g_alpha,
+                               const void *Wh, const void *Whh, void *dG, void *partial,
+                               void *head_partial, void *stream);
+
 /* Y = X W (+ bias), the two time-batched products of that network's LSTM outside the
  * recurrences: layer 1's input projection of all steps (K = 128, N = 512, W = weight_ih_l1
  * transposed, bias = b_ih + b_hh) and the gradient layer 1 hands to layer 0 (K = 512,

@@ -58,7 +58,8 @@ __device__ __forceinline__ float2 load_streaming(const float* p) {
         hipStream_t stream
 #define KVAE_LSTM128_BWD_ARGS                                                                   \
     const float *x, const float *Wih, const float *gates, const float *c, const float *c_init,  \
-        const float *g_h, const float *Whh, float *dG, float *dx, float *partial,               \
+        const float *g_h, const float *Whh, float *dG, float *dx, float *partial, int KH,       \
+        const float *alpha, const float *g_alpha, const float *Wh, float *head_partial,         \
         hipStream_t stream
 int launch_lstm128_forward_tiles(int T, int B, int P, int workgroups, KVAE_LSTM128_FWD_ARGS);
 int launch_lstm128_forward_tiles_split(int T, int B, int P, int workgroups, KVAE_LSTM128_FWD_ARGS);

@@ -477,8 +477,23 @@ int KVAE_LAUNCH_TILES(int T, int B, int P, int workgroups, const float* x,
 
 // what the cell adjoint of one step reads from global memory for this lane's 4 rows x 2
 // units; independent of the recurrence, so loaded a step ahead
+template <int KH>
 struct CellRows {
     float2 ig[4], fg[4], gg[4], og[4], cc[4], cp[4], gh[4];
+    // softmax output and its gradient: lane (lane & 3) = k of every quad holds entry k of
+    // each of the lane's four rows (every lane of a row group would hold the same KH values)
+    float al[4], ga[4];
+};
+
+// The softmax head on top of the layer, alpha = softmax(h W^T + b) with W (KH,H)
+// (kvae/dynamics_parameter_network.py:57-58): with KH > 0 the kernel forms the gradient
+// w.r.t. h_t from alpha_t and its gradient instead of reading it, and sums dW, db.
+// alpha, g_alpha: (T,B,KH); partial[blockIdx.x][ KH*H | KH ].
+struct HeadAdjoint {
+    const float* alpha;
+    const float* g_alpha;
+    const float* W;
+    float* partial;
 };
 
 // grid = ceil(B/16), block = 256.  g_h (T,B,H): gradient w.r.t. every h_t from above.
@@ -486,13 +501,13 @@ struct CellRows {
 // partial[blockIdx.x][ 4H | 4H | 4H*P ]: per-workgroup sums over (t, rows) of dG (twice:
 // bias_ih and bias_hh each get memory of their own) and, for P > 0, of dG^T x (the input
 // weight gradient); for P > 0 also dx (T,B,P) = dG Wih.
-template <int P, bool FULL>
+template <int P, bool FULL, int KH>
 __device__ __forceinline__ void
 lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __restrict__ Wih,
                       const float* __restrict__ gates, const float* __restrict__ cg,
                       const float* __restrict__ c_init, const float* __restrict__ g_h,
                       const float* __restrict__ Whh, float* __restrict__ dG,
-                      float* __restrict__ dx, float* __restrict__ partial,
+                      float* __restrict__ dx, float* __restrict__ partial, const HeadAdjoint head,
                       KVAE_GTILE_T, float (&dx_part)[2][4][16][P > 0 ? P : 1]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, s = lane >> 4;
     const int r0 = blockIdx.x * 16, u0 = 32 * wave, ub = u0 + 2 * cc;
@@ -545,7 +560,14 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     }
     // c_t of step t is c_{t-1} of step t+1, which the previous iteration already holds: only
     // the first step (t = T-1) reads it from memory
-    auto load_rows = [&](int t, CellRows& in) {
+    float wh[KH > 0 ? KH : 1][2], hw[KH > 0 ? KH : 1][2], hb = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        wh[k][0] = head.W[k * RH + ub];
+        wh[k][1] = head.W[k * RH + ub + 1];
+        hw[k][0] = hw[k][1] = 0.f;
+    }
+    auto load_rows = [&](int t, CellRows<KH>& in) {
         const float2 z = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -566,12 +588,18 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                 } else if (c_init) {
                     in.cp[i] = *reinterpret_cast<const float2*>(c_init + o);
                 }
-                in.gh[i] = load_streaming(g_h + t * BH + o);
+                if (KH == 0) in.gh[i] = load_streaming(g_h + t * BH + o);
+            }
+            if (KH > 0) {
+                const int k = cc & 3;
+                const bool ok = (FULL || row < B) && k < KH;
+                in.al[i] = ok ? head.alpha[((long)t * B + row) * KH + k] : 0.f;
+                in.ga[i] = ok ? head.g_alpha[((long)t * B + row) * KH + k] : 0.f;
             }
         }
     };
 
-    CellRows in;
+    CellRows<KH> in;
 #pragma unroll
     for (int i = 0; i < 4; ++i) in.cp[i] = make_float2(0.f, 0.f);
     load_rows(T - 1, in);
@@ -592,10 +620,31 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int lr = 4 * s + i;
-            const float dh0 = rec[0][i] + in.gh[i].x, dh1 = rec[1][i] + in.gh[i].y;
+            float2 gh = in.gh[i];
+            const float tc0 = tanhf_(in.cc[i].x), tc1 = tanhf_(in.cc[i].y);
+            if (KH > 0) {
+                // softmax adjoint of this row, then d h = dl W; dW += dl^T h with h = o tanh(c)
+                float dot = in.al[i] * in.ga[i];           // sum over the quad's lanes = over k
+                dot += row_exchange16<0xB1>(dot);
+                dot += row_exchange16<0x4E>(dot);
+                const float dl_own = in.al[i] * (in.ga[i] - dot);
+                hb += dl_own;
+                const float h0v = in.og[i].x * tc0, h1v = in.og[i].y * tc1;
+                gh = make_float2(0.f, 0.f);
+                const float dl[4] = {row_exchange16<0x00>(dl_own), row_exchange16<0x55>(dl_own),
+                                     row_exchange16<0xAA>(dl_own), row_exchange16<0xFF>(dl_own)};
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    gh.x += dl[k] * wh[k][0];
+                    gh.y += dl[k] * wh[k][1];
+                    hw[k][0] += dl[k] * h0v;
+                    hw[k][1] += dl[k] * h1v;
+                }
+            }
+            const float dh0 = rec[0][i] + gh.x, dh1 = rec[1][i] + gh.y;
             float2 di, df, dg, dout;
             {
-                const float tc = tanhf_(in.cc[i].x);
+                const float tc = tc0;
                 const float dct = dh0 * in.og[i].x * (1.f - tc * tc) + dc[i][0];
                 di.x = dct * in.gg[i].x * in.ig[i].x * (1.f - in.ig[i].x);
                 df.x = dct * in.cp[i].x * in.fg[i].x * (1.f - in.fg[i].x);
@@ -604,7 +653,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                 dc[i][0] = dct * in.fg[i].x;
             }
             {
-                const float tc = tanhf_(in.cc[i].y);
+                const float tc = tc1;
                 const float dct = dh1 * in.og[i].y * (1.f - tc * tc) + dc[i][1];
                 di.y = dct * in.gg[i].y * in.ig[i].y * (1.f - in.ig[i].y);
                 df.y = dct * in.cp[i].y * in.fg[i].y * (1.f - in.fg[i].y);
@@ -612,10 +661,22 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
                 dout.y = dh1 * tc * in.og[i].y * (1.f - in.og[i].y);
                 dc[i][1] = dct * in.fg[i].y;
             }
-            dgs[i][0] = di;
-            dgs[i][1] = df;
-            dgs[i][2] = dg;
-            dgs[i][3] = dout;
+            if (KH > 0) {
+                // with the head's accumulators in the kernel the registers for deferred
+                // stores are not there: the row's gate gradients go out at once
+                if (FULL || r0 + lr < B) {
+                    float* go = dG + t * BG + (long)(r0 + lr) * RG4 + ub;
+                    store_streaming(go, di);
+                    store_streaming(go + RH, df);
+                    store_streaming(go + 2 * RH, dg);
+                    store_streaming(go + 3 * RH, dout);
+                }
+            } else {
+                dgs[i][0] = di;
+                dgs[i][1] = df;
+                dgs[i][2] = dg;
+                dgs[i][3] = dout;
+            }
             const float2 dgt[4] = {di, df, dg, dout};
 #ifdef KVAE_LSTM_BF16X3
 #pragma unroll
@@ -669,29 +730,32 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
         // instructions (issued together, every compute unit would write at the same moment
         // and wait for memory while the matrix pipe idles)
         auto store_dg = [&](int idx) {
+            if (KH > 0) return;
             const int i = idx >> 2, g = idx & 3;
             if (FULL || r0 + 4 * s + i < B) store_streaming(dG + t * BG + (long)(r0 + 4 * s + i) * RG4 + g * RH + ub, dgs[i][g]);
         };
 #ifdef KVAE_LSTM_BF16X3
         if (t > 0) {
             // A operands: row cc of the gate-gradient tile, elements 32 kk + 8 s .. + 7; read
-            // two k-groups ahead of the matrix instructions that use them
+            // AG k-groups ahead of the matrix instructions that use them (one with the softmax
+            // head's accumulators in the kernel, which needs the registers)
+            constexpr int AG = KH > 0 ? 1 : 2;
             const int a_off = cc * RLDGB + 8 * s;
-            bf16x8 ah[2][2], al[2][2];
-            auto read_group = [&](int grp, bf16x8 (&h_)[2], bf16x8 (&l_)[2]) {
+            bf16x8 ah[2][AG], al[2][AG];
+            auto read_group = [&](int grp, bf16x8 (&h_)[AG], bf16x8 (&l_)[AG]) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    h_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].hi[a_off + 32 * (2 * grp + q)]);
-                    l_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].lo[a_off + 32 * (2 * grp + q)]);
+                for (int q = 0; q < AG; ++q) {
+                    h_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].hi[a_off + 32 * (AG * grp + q)]);
+                    l_[q] = *reinterpret_cast<const bf16x8*>(&tile[t & 1].lo[a_off + 32 * (AG * grp + q)]);
                 }
             };
             read_group(0, ah[0], al[0]);
 #pragma unroll
-            for (int grp = 0; grp < 8; ++grp) {
-                if (grp < 7) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
+            for (int grp = 0; grp < 16 / AG; ++grp) {
+                if (grp + 1 < 16 / AG) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int kk = 2 * grp + q;
+                for (int q = 0; q < AG; ++q) {
+                    const int kk = AG * grp + q;
                     rec[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], whi[0][kk], rec[0], 0, 0, 0);
                     rec[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], whi[1][kk], rec[1], 0, 0, 0);
                     rec[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[grp & 1][q], whi[0][kk], rec[0], 0, 0, 0);
@@ -724,6 +788,27 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
         // tile[t & 1] is rewritten in step t-2, after the barrier of step t-1 that every
         // wavefront reaches only after its reads above
     }
+    if (KH > 0) {
+        // every lane of the workgroup that owns row group s saw the same dl: the weight sums
+        // are per unit (lanes with s == 0 write after adding the four row groups), the bias
+        // sums are taken from one lane per row group
+        float* hp = head.partial + (long)blockIdx.x * (KH * (RH + 1));
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float v = hw[k][hf];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (s == 0) hp[k * RH + ub + hf] = v;
+            }
+        }
+        // lane k of a quad summed d logit_k of its rows
+        float b = hb;
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (threadIdx.x < KH) hp[KH * RH + threadIdx.x] = b;
+    }
     // sum the per-lane column accumulators over the four row groups (lane bits 4, 5)
     float* part = partial + (long)blockIdx.x * (RG4 * (2 + P));
 #pragma unroll
@@ -749,14 +834,14 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     }
 }
 
-template <int P>
+template <int P, int KH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 KVAE_BWD_KERNEL(int T, int B, const float* __restrict__ x,
                                  const float* __restrict__ Wih, const float* __restrict__ gates,
                                  const float* __restrict__ cg, const float* __restrict__ c_init,
                                  const float* __restrict__ g_h, const float* __restrict__ Whh,
                                  float* __restrict__ dG, float* __restrict__ dx,
-                                 float* __restrict__ partial) {
+                                 float* __restrict__ partial, const HeadAdjoint head) {
 #ifdef KVAE_LSTM_BF16X3
     __shared__ __attribute__((aligned(16))) GTile tile[2];
 #else
@@ -765,8 +850,8 @@ KVAE_BWD_KERNEL(int T, int B, const float* __restrict__ x,
     __shared__ float dx_part[2][4][16][P > 0 ? P : 1];
     // (one body for full and ragged tiles: a second, unpredicated instance costs registers
     // the resident matrix needs)
-    lstm128_backward_body<P, false>(T, B, x, Wih, gates, cg, c_init, g_h, Whh, dG, dx, partial,
-                                    tile, dx_part);
+    lstm128_backward_body<P, false, KH>(T, B, x, Wih, gates, cg, c_init, g_h, Whh, dG, dx,
+                                        partial, head, tile, dx_part);
 }
 
 // single-tile launchers of this build (the C entry points below pick a build)
@@ -791,11 +876,29 @@ int KVAE_LAUNCH_FWD(int T, int B, int P, const float* x, const float* Wih, const
 
 int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const float* gates,
                     const float* c, const float* c_init, const float* g_h, const float* Whh,
-                    float* dG, float* dx, float* partial, hipStream_t stream) {
+                    float* dG, float* dx, float* partial, int KH, const float* alpha,
+                    const float* g_alpha, const float* Wh, float* head_partial,
+                    hipStream_t stream) {
     const dim3 grid((B + 15) / 16);
+    const HeadAdjoint head = {alpha, g_alpha, Wh, head_partial};
+    if (KH > 0) {
+        // the head sits on the upper layer, whose input projection is never formed in the kernel
+        if (P != 0) return KVAE_E_UNSUPPORTED;
+#define KVAE_R128H(K_)                                                                       \
+    case K_:                                                                                 \
+        hipLaunchKernelGGL((KVAE_BWD_KERNEL<0, K_>), grid, dim3(256), 0, stream, T, B, x, Wih, \
+                           gates, c, c_init, g_h, Whh, dG, dx, partial, head);               \
+        break;
+        switch (KH) {
+            KVAE_R128H(2) KVAE_R128H(3) KVAE_R128H(4)
+            default: return KVAE_E_UNSUPPORTED;
+        }
+#undef KVAE_R128H
+        return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+    }
 #define KVAE_R128B(P_)                                                                    \
-    hipLaunchKernelGGL(KVAE_BWD_KERNEL<P_>, grid, dim3(256), 0, stream, T, B, x, Wih, gates, \
-                       c, c_init, g_h, Whh, dG, dx, partial)
+    hipLaunchKernelGGL((KVAE_BWD_KERNEL<P_, 0>), grid, dim3(256), 0, stream, T, B, x, Wih, gates, \
+                       c, c_init, g_h, Whh, dG, dx, partial, head)
     switch (P) {
         case 0: KVAE_R128B(0); break;
         case 1: KVAE_R128B(1); break;
@@ -882,7 +985,21 @@ int kvae_lstm128_backward(int T, int B, int P, const void* x, const void* Wih, c
     return (split_products() ? launch_lstm128_backward_split : launch_lstm128_backward_exact)(
         T, B, P, (const float*)x, (const float*)Wih, (const float*)gates, (const float*)c,
         (const float*)c_init, (const float*)g_h, (const float*)Whh, (float*)dG, (float*)dx,
-        (float*)partial, (hipStream_t)stream);
+        (float*)partial, 0, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int kvae_lstm128_backward_head(int T, int B, int K, const void* gates, const void* c,
+                               const void* c_init, const void* alpha, const void* g_alpha,
+                               const void* Wh, const void* Whh, void* dG, void* partial,
+                               void* head_partial, void* stream) {
+    if (T < 1 || B < 1 || !gates || !c || !alpha || !g_alpha || !Wh || !Whh || !dG || !partial ||
+        !head_partial)
+        return KVAE_E_BADARG;
+    if (K < 2 || K > 4) return KVAE_E_UNSUPPORTED;
+    return (split_products() ? launch_lstm128_backward_split : launch_lstm128_backward_exact)(
+        T, B, 0, nullptr, nullptr, (const float*)gates, (const float*)c, (const float*)c_init,
+        nullptr, (const float*)Whh, (float*)dG, nullptr, (float*)partial, K, (const float*)alpha,
+        (const float*)g_alpha, (const float*)Wh, (float*)head_partial, (hipStream_t)stream);
 }
 
 }  // extern "C"

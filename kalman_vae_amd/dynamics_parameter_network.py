@@ -57,7 +57,13 @@ class LSTMModel(nn.Module):
         self.count += 1
         if (self.use_hip_recurrence and self.hidden is None and x.size(0) > 1
                 and lstm_function.supported(x, self.hidden_dim)):
-            # whole sequence from a fresh state: recurrence on the HIP kernels
+            # whole sequence from a fresh state: recurrence on the HIP kernels (the default
+            # network as one node: its backward forms the head's adjoint inside the upper
+            # layer's kernel)
+            fused = lstm_function.fused_lstm_head(x, self.lstm, self.linear, lead)
+            if fused is not None:
+                self.hidden = fused[1]
+                return fused[0]
             h, hidden = lstm_function.fused_lstm(x, self.lstm)
             self.hidden = (hidden if isinstance(hidden, lstm_function.LastState)
                            else (hidden[0].detach(), hidden[1].detach()))

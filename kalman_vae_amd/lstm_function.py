@@ -240,41 +240,129 @@ def _rows_matmul(x2, w, bias, out):
     return torch.mm(x2, w, out=out)
 
 
+def _resident_forward(x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+    """Both layers through kvae_lstm128_forward: (gates0, h0, c0, gates1, h1, c1)."""
+    lib = capi.load()
+    T, B, P = x.shape
+    H = 128
+    new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
+    gates0, h0, c0 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+    gates1, h1, c1 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
+    whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1,
+                                                  b_hh1)
+    wih0 = w_ih0.contiguous()
+    stream = capi.current_stream_ptr()
+    if P <= 4:
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
+            gates0.data_ptr(), h0.data_ptr(), c0.data_ptr(), None, None, 1, stream))
+    else:
+        # a wide input: its projection of all steps is one library GEMM, like layer 1's
+        torch.addmm(b0, x.view(T * B, P), wih0.t(), out=gates0.view(T * B, 4 * H))
+        capi.check(lib.kvae_lstm128_forward(
+            T, B, 0, None, None, None, whh0t.data_ptr(), gates0.data_ptr(), h0.data_ptr(),
+            c0.data_ptr(), None, None, 1, stream))
+    # layer 1's input projection of all steps: (T*B,128) x (128,512) + bias
+    _rows_matmul(h0.view(T * B, H), wih1t, b1, gates1.view(T * B, 4 * H))
+    capi.check(lib.kvae_lstm128_forward(
+        T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
+        c1.data_ptr(), None, None, 1, stream))
+    return gates0, h0, c0, gates1, h1, c1
+
+
+def _resident_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1, g_h1=None,
+                       head=None):
+    """Adjoint of _resident_forward.  Either g_h1 (T,B,H), the gradient w.r.t. the upper
+    layer's h, or head = (alpha (T,B,K), g_alpha (T,B,K), W (K,H)): the softmax head's adjoint
+    runs inside the upper layer's kernel, and (dW_head, db_head) are appended to the result."""
+    lib = capi.load()
+    T, B, P = x.shape
+    H = 128
+    dG0, dG1 = torch.empty_like(gates0), torch.empty_like(gates1)
+    dx = torch.empty_like(x)
+    blocks = lib.kvae_lstm128_blocks(B)
+    part1 = torch.empty(blocks, 4 * H * 2, dtype=x.dtype, device=x.device)
+    Pk = P if P <= 4 else 0          # input dimension the layer-0 kernel handles itself
+    part0 = torch.empty(blocks, 4 * H * (2 + Pk), dtype=x.dtype, device=x.device)
+    wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
+    stream = capi.current_stream_ptr()
+    parth = None
+    if head is None:
+        capi.check(lib.kvae_lstm128_backward(
+            T, B, 0, None, None, gates1.data_ptr(), c1.data_ptr(), None, g_h1.data_ptr(),
+            whh1.data_ptr(), dG1.data_ptr(), None, part1.data_ptr(), stream))
+    else:
+        alpha, g_alpha, w_head = head
+        K = w_head.shape[0]
+        parth = torch.empty(blocks, K * (H + 1), dtype=x.dtype, device=x.device)
+        capi.check(lib.kvae_lstm128_backward_head(
+            T, B, K, gates1.data_ptr(), c1.data_ptr(), None, alpha.data_ptr(), g_alpha.data_ptr(),
+            w_head.data_ptr(), whh1.data_ptr(), dG1.data_ptr(), part1.data_ptr(),
+            parth.data_ptr(), stream))
+    d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
+    # gradient w.r.t. layer 0's h through layer 1's input product
+    g_h0 = _rows_matmul(d1, wih1, None, torch.empty(T * B, H, dtype=x.dtype,
+                                                    device=x.device)).view(T, B, H)
+    if Pk:
+        capi.check(lib.kvae_lstm128_backward(
+            T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
+            g_h0.data_ptr(), whh0.data_ptr(), dG0.data_ptr(), dx.data_ptr(),
+            part0.data_ptr(), stream))
+    else:
+        capi.check(lib.kvae_lstm128_backward(
+            T, B, 0, None, None, gates0.data_ptr(), c0.data_ptr(), None, g_h0.data_ptr(),
+            whh0.data_ptr(), dG0.data_ptr(), None, part0.data_ptr(), stream))
+    split = T > 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1
+    sums = [part1, part0] + ([parth] if parth is not None else [])
+    if split:
+        # dG0^T h0_{t-1}, dG1^T h0_t, dG1^T h1_{t-1}: one launch each into one buffer of
+        # per-slab results; ONE launch then sums the slabs of all three and the per-workgroup
+        # bias / input-weight (/ head) partial sums
+        R, E = T * B, 4 * H * H
+        S = lib.kvae_lstm128_wgrad_slabs(R)
+        slabs = torch.empty(S, 3 * E, dtype=x.dtype, device=x.device)
+        for i, (dg, hh, shift) in enumerate(((d0, h0, B), (d1, h0, 0), (d1, h1, B))):
+            capi.check(lib.kvae_lstm128_wgrad(R, dg.data_ptr(), hh.data_ptr(), shift,
+                                              slabs[:, i * E:].data_ptr(), 3 * E, stream))
+        sums.append(slabs)
+    sums = capi.column_sum_many(sums)
+    s1, s0 = sums[0], sums[1]
+    db1, db1b = s1[:4 * H], s1[4 * H:]
+    db0, db0b = s0[:4 * H], s0[4 * H:8 * H]
+    if Pk:
+        dw_ih0 = s0[8 * H:].view(4 * H, P)
+    else:
+        torch.mm(d0, wih0, out=dx.view(T * B, P))
+        dw_ih0 = _splitk_tn(d0, x.view(T * B, P))
+    zero = lambda w: torch.zeros_like(w)
+    if split:
+        dw_hh0, dw_ih1, dw_hh1 = sums[-1].view(3, 4 * H, H).unbind(0)
+    elif T > 1:
+        dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
+            (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),
+            (d1[B:], h1[:-1].reshape(-1, H))])
+    else:
+        dw_hh0, dw_ih1, dw_hh1 = zero(w_hh0), _splitk_tn(d1, h0.reshape(T * B, H)), zero(w_hh1)
+    out = (dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b)
+    if parth is not None:
+        sh = sums[2]
+        K = head[2].shape[0]
+        out += (sh[:K * H].view(K, H), sh[K * H:])
+    return out
+
+
 class ResidentLSTM2Function(torch.autograd.Function):
-    """Two layers, hidden size 128, layer-0 input dimension <= 4, one launch per layer and
-    direction with the layer's recurrent matrix resident in registers
-    (kvae_lstm128_forward / _backward).  Layer 1's input product over all steps and the
-    product that carries the gradient from layer 1 to layer 0 are time-batched library
-    GEMMs; so are the three recurrent / input weight gradients."""
+    """Two layers, hidden size 128, one launch per layer and direction with the layer's
+    recurrent matrix resident in registers (kvae_lstm128_forward / _backward).  Layer 1's
+    input product over all steps, the product that carries the gradient from layer 1 to
+    layer 0 and the three recurrent / input weight gradients are the library's own
+    time-batched kernels (library GEMMs with the exact-fp32 product form)."""
 
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
-        lib = capi.load()
-        T, B, P = x.shape
-        H = 128
         x = x.contiguous()
-        new = lambda *s: torch.empty(s, dtype=x.dtype, device=x.device)
-        gates0, h0, c0 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
-        gates1, h1, c1 = new(T, B, 4 * H), new(T, B, H), new(T, B, H)
-        whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1,
-                                                      b_hh1)
-        wih0 = w_ih0.contiguous()
-        stream = capi.current_stream_ptr()
-        if P <= 4:
-            capi.check(lib.kvae_lstm128_forward(
-                T, B, P, x.data_ptr(), wih0.data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
-                gates0.data_ptr(), h0.data_ptr(), c0.data_ptr(), None, None, 1, stream))
-        else:
-            # a wide input: its projection of all steps is one library GEMM, like layer 1's
-            torch.addmm(b0, x.view(T * B, P), wih0.t(), out=gates0.view(T * B, 4 * H))
-            capi.check(lib.kvae_lstm128_forward(
-                T, B, 0, None, None, None, whh0t.data_ptr(), gates0.data_ptr(), h0.data_ptr(),
-                c0.data_ptr(), None, None, 1, stream))
-        # layer 1's input projection of all steps: (T*B,128) x (128,512) + bias
-        _rows_matmul(h0.view(T * B, H), wih1t, b1, gates1.view(T * B, 4 * H))
-        capi.check(lib.kvae_lstm128_forward(
-            T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
-            c1.data_ptr(), None, None, 1, stream))
+        gates0, h0, c0, gates1, h1, c1 = _resident_forward(x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1,
+                                                           w_hh1, b_ih1, b_hh1)
         ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
         ctx.mark_non_differentiable(h0, c0, c1)
         ctx.set_materialize_grads(False)
@@ -282,67 +370,48 @@ class ResidentLSTM2Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_h1, _dh0, _dc0, _dc1):
+        return _resident_backward(*ctx.saved_tensors, g_h1=g_h1.contiguous())
+
+
+class ResidentLSTM2HeadFunction(torch.autograd.Function):
+    """ResidentLSTM2Function followed by the softmax head alpha = softmax(h1 W^T + b) as ONE
+    autograd node: the head's adjoint runs inside the upper layer's backward kernel
+    (kvae_lstm128_backward_head), which neither reads a gradient w.r.t. h1 nor needs the
+    head's own backward launch and reduction.  K in 2..4, split product form."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_head, b_head,
+                lead):
         lib = capi.load()
-        x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
-        T, B, P = x.shape
-        H = 128
-        g_h1 = g_h1.contiguous()
-        dG0, dG1 = torch.empty_like(gates0), torch.empty_like(gates1)
-        dx = torch.empty_like(x)
-        blocks = lib.kvae_lstm128_blocks(B)
-        part1 = torch.empty(blocks, 4 * H * 2, dtype=x.dtype, device=x.device)
-        Pk = P if P <= 4 else 0          # input dimension the layer-0 kernel handles itself
-        part0 = torch.empty(blocks, 4 * H * (2 + Pk), dtype=x.dtype, device=x.device)
-        wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
-        stream = capi.current_stream_ptr()
-        capi.check(lib.kvae_lstm128_backward(
-            T, B, 0, None, None, gates1.data_ptr(), c1.data_ptr(), None, g_h1.data_ptr(),
-            whh1.data_ptr(), dG1.data_ptr(), None, part1.data_ptr(), stream))
-        d0, d1 = dG0.view(T * B, 4 * H), dG1.view(T * B, 4 * H)
-        # gradient w.r.t. layer 0's h through layer 1's input product
-        g_h0 = _rows_matmul(d1, wih1, None, torch.empty(T * B, H, dtype=x.dtype,
-                                                        device=x.device)).view(T, B, H)
-        if Pk:
-            capi.check(lib.kvae_lstm128_backward(
-                T, B, P, x.data_ptr(), wih0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), None,
-                g_h0.data_ptr(), whh0.data_ptr(), dG0.data_ptr(), dx.data_ptr(),
-                part0.data_ptr(), stream))
-        else:
-            capi.check(lib.kvae_lstm128_backward(
-                T, B, 0, None, None, gates0.data_ptr(), c0.data_ptr(), None, g_h0.data_ptr(),
-                whh0.data_ptr(), dG0.data_ptr(), None, part0.data_ptr(), stream))
-        split = T > 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1
-        slabs = None
-        if split:
-            # dG0^T h0_{t-1}, dG1^T h0_t, dG1^T h1_{t-1}: one launch each into one buffer of
-            # per-slab results; ONE launch then sums the slabs of all three and the two
-            # layers' per-workgroup bias / input-weight partial sums
-            R, E = T * B, 4 * H * H
-            S = lib.kvae_lstm128_wgrad_slabs(R)
-            slabs = torch.empty(S, 3 * E, dtype=x.dtype, device=x.device)
-            for i, (dg, hh, shift) in enumerate(((d0, h0, B), (d1, h0, 0), (d1, h1, B))):
-                capi.check(lib.kvae_lstm128_wgrad(R, dg.data_ptr(), hh.data_ptr(), shift,
-                                                  slabs[:, i * E:].data_ptr(), 3 * E, stream))
-            s1, s0, sw = capi.column_sum_many([part1, part0, slabs])
-        else:
-            s1, s0 = capi.column_sum(part1), capi.column_sum(part0)
-        db1, db1b = s1[:4 * H], s1[4 * H:]
-        db0, db0b = s0[:4 * H], s0[4 * H:8 * H]
-        if Pk:
-            dw_ih0 = s0[8 * H:].view(4 * H, P)
-        else:
-            torch.mm(d0, wih0, out=dx.view(T * B, P))
-            dw_ih0 = _splitk_tn(d0, x.view(T * B, P))
-        zero = lambda w: torch.zeros_like(w)
-        if split:
-            dw_hh0, dw_ih1, dw_hh1 = sw.view(3, 4 * H, H).unbind(0)
-        elif T > 1:
-            dw_hh0, dw_ih1, dw_hh1 = _splitk_tn_many([
-                (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(T * B, H)),
-                (d1[B:], h1[:-1].reshape(-1, H))])
-        else:
-            dw_hh0, dw_ih1, dw_hh1 = zero(w_hh0), _splitk_tn(d1, h0.reshape(T * B, H)), zero(w_hh1)
-        return dx, dw_ih0, dw_hh0, db0, db0b, dw_ih1, dw_hh1, db1, db1b
+        x = x.contiguous()
+        T, B, _ = x.shape
+        H, K = 128, w_head.shape[0]
+        gates0, h0, c0, gates1, h1, c1 = _resident_forward(x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1,
+                                                           w_hh1, b_ih1, b_hh1)
+        wc = w_head.contiguous()
+        lead_rows = B if lead else 0
+        out = torch.empty(lead_rows + T * B, K, dtype=x.dtype, device=x.device)
+        capi.check(lib.kvae_softmax_head_forward(T * B, H, K, h1.data_ptr(), wc.data_ptr(),
+                                                 b_head.contiguous().data_ptr(), out.data_ptr(),
+                                                 lead_rows, capi.current_stream_ptr()))
+        ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1, wc,
+                              out)
+        ctx.lead_rows = lead_rows
+        ctx.mark_non_differentiable(h1, h0, c0, c1)
+        ctx.set_materialize_grads(False)
+        return out.view(T + (1 if lead else 0), B, K), h1, h0, c0, c1
+
+    @staticmethod
+    def backward(ctx, g_alpha, _dh1, _dh0, _dc0, _dc1):
+        if g_alpha is None:
+            return (None,) * 12
+        *saved, wc, out = ctx.saved_tensors
+        x = saved[0]
+        T, B, _ = x.shape
+        K = wc.shape[0]
+        g = g_alpha.contiguous().view(-1, K)[ctx.lead_rows:]
+        grads = _resident_backward(*saved, head=(out[ctx.lead_rows:], g, wc))
+        return grads + (None,)
 
 
 class SoftmaxHeadFunction(torch.autograd.Function):
@@ -514,6 +583,25 @@ def fused_lstm(x, lstm):
         return out, LastState((h0[-1], out.detach()[-1]), (c0[-1], c1[-1]))
     out, h_n, c_n = FusedLSTMFunction.apply(x, *params)
     return out, (h_n, c_n)
+
+
+def fused_lstm_head(x, lstm, linear, lead=False):
+    """softmax(linear(lstm(x))) for the default network (two layers of 128 units, 2 to 4
+    softmax outputs) as one autograd node whose backward runs the head's adjoint inside the
+    upper layer's kernel; None when this form does not apply (use fused_lstm and
+    softmax_head).  Returns (weights, state to continue from)."""
+    K = linear.out_features
+    if not (RESIDENT and PERSISTENT and lstm.num_layers == 2 and lstm.hidden_size == 128
+            and not lstm.bidirectional and 2 <= K <= 4 and x.dtype == torch.float32
+            and linear.bias is not None):
+        return None
+    params = []
+    for l in range(2):
+        params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"),
+                   getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")]
+    alpha, h1, h0, c0, c1 = ResidentLSTM2HeadFunction.apply(x, *params, linear.weight, linear.bias,
+                                                            lead)
+    return alpha, LastState((h0[-1], h1[-1]), (c0[-1], c1[-1]))
 
 
 class LastState:

@@ -304,3 +304,38 @@ def test_column_sum_many_equals_separate_sums():
     assert len(capi.column_sum_many(xs[:1])) == 1
     with pytest.raises(RuntimeError):
         capi.column_sum_many(xs + xs[:1])
+
+
+@pytest.mark.parametrize("T,B,P,K,lead", [(20, 70, 2, 3, True), (5, 33, 4, 2, False),
+                                          (9, 256, 2, 4, True), (2, 1, 1, 3, False)])
+def test_lstm_with_head_in_one_node_matches_separate_nodes(T, B, P, K, lead):
+    """fused_lstm_head (the softmax head's adjoint inside the upper layer's backward kernel)
+    against fused_lstm followed by softmax_head, and both against torch: weights, every
+    parameter gradient, the state to continue from."""
+    import kalman_vae_amd.lstm_function as lf
+    torch.manual_seed(T * 7 + B + K)
+    dev = torch.device("cuda:0")
+    lstm = torch.nn.LSTM(P, 128, num_layers=2).to(dev)
+    lin = torch.nn.Linear(128, K).to(dev)
+    x = torch.randn(T, B, P, device=dev, requires_grad=True)
+    w = torch.randn(T + (1 if lead else 0), B, K, device=dev)
+    params = [x] + list(lstm.parameters()) + list(lin.parameters())
+    fused = lf.fused_lstm_head(x, lstm, lin, lead)
+    assert fused is not None
+    a1, st1 = fused
+    g1 = torch.autograd.grad((a1 * w).sum(), params)
+    h, st2 = lf.fused_lstm(x, lstm)
+    a2 = lf.softmax_head(h, lin, lead)
+    g2 = torch.autograd.grad((a2 * w).sum(), params)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref = torch.softmax(lin(lstm(x)[0]), -1)
+    if lead:
+        ref = torch.cat([torch.full((1, B, K), 1.0 / K, device=dev), ref])
+    g3 = torch.autograd.grad((ref * w).sum(), params)
+    assert torch.equal(a1, a2) and rel_err(a1, ref) < 1e-5
+    for (hh1, cc1), (hh2, cc2) in [(st1.get(), st2.get())]:
+        assert torch.equal(hh1, hh2) and torch.equal(cc1, cc2)
+    names = ["x"] + [n for n, _ in lstm.named_parameters()] + ["linear.weight", "linear.bias"]
+    bad = [(n, rel_err(a, b), rel_err(a, c)) for n, a, b, c in zip(names, g1, g2, g3)
+           if not (rel_err(a, b) < 2e-5 and rel_err(a, c) < 1e-4)]
+    assert not bad, bad
