@@ -694,7 +694,7 @@ def main():
         # c3's default is the network the one-launch masked filter holds in LDS; every other
         # configuration uses the reference's default network
         args.net = "mlp" if args.config == "c3" else "lstm"
-    defaults = {"c1": (50, 10), "c2": (50, 10), "c3": (3, 1), "c4": (3, 1), "c5": (10, 3)}
+    defaults = {"c1": (50, 10), "c2": (50, 10), "c3": (5, 2), "c4": (3, 1), "c5": (10, 3)}
     if args.steps is None:
         args.steps = defaults[args.config][0]
     if args.warmup is None:

@@ -37,6 +37,14 @@ for _ in range(3):
     lib.kvae_lstm128_backward(T, B, 0, None, None, gates.data_ptr(), c.data_ptr(), None,
                               g_h.data_ptr(), whh.data_ptr(), dG.data_ptr(), None, part.data_ptr(),
                               st)
+    KH = 3
+    al = torch.softmax(new(T, B, KH), -1)
+    gal = 1e-3 * new(T, B, KH)
+    wh = 0.1 * new(KH, H)
+    hpart = new(lib.kvae_lstm128_blocks(B), KH * (H + 1))
+    lib.kvae_lstm128_backward_head(T, B, KH, gates.data_ptr(), c.data_ptr(), None, al.data_ptr(),
+                                   gal.data_ptr(), wh.data_ptr(), whh.data_ptr(), dG.data_ptr(),
+                                   part.data_ptr(), hpart.data_ptr(), st)
     R = T * B
     wih1 = 0.08 * new(4 * H, H)
     wih1t = wih1.t().contiguous()
