@@ -513,6 +513,24 @@ int kvae_lstm128_backward_head(int T, int B, int K, const void *gates, const voi
                                const void *Wh, const void *Whh, void *dG, void *partial,
                                void *head_partial, void *stream);
 
+/* ONE time step of one layer of that LSTM (hidden size 128) over B rows, input projection
+ * included: gates = x W_ih^T + h_prev W_hh^T + bias, c = f c_prev + i g, h = o tanh(c) -- one
+ * step of torch.nn.LSTM as the masked filter calls the network once per time step
+ * (kvae/state_space_model.py:279-282, kvae/dynamics_parameter_network.py:46-58).
+ * P == 0, the upper layer: x (B,128), Wx = W_ih transposed (128,512); each workgroup keeps
+ *   the slice of both matrices that belongs to 64 hidden units in registers, so the (B,512)
+ *   projection never goes through memory (3.5 KB per row instead of 6.5 KB for
+ *   kvae_rowstream_matmul + kvae_lstm128_forward).
+ * P in 1..2, the lower layer: x (B,P), Wx = W_ih as stored (512,P), projected with plain
+ *   multiply-adds (2 KB per row); wider inputs: KVAE_E_UNSUPPORTED (kvae_lstm128_forward).
+ * h_prev, c_prev, h_out, c_out (B,128); h_prev and c_prev both NULL for the zero state;
+ * WhhT (128,512) = W_hh transposed; bias (512) = b_ih + b_hh.  float32; h_prev (and x for
+ * P == 0) 16-byte aligned.  Several tiles of rows are kept in flight per compute unit.
+ * Split product form.                                                                   */
+int kvae_lstm128_step_fused(long B, int P, const void *x, const void *Wx, const void *h_prev,
+                            const void *c_prev, const void *WhhT, const void *bias, void *h_out,
+                            void *c_out, void *stream);
+
 /* Y = X W (+ bias), the two time-batched products of that network's LSTM outside the
  * recurrences: layer 1's input projection of all steps (K = 128, N = 512, W = weight_ih_l1
  * transposed, bias = b_ih + b_hh) and the gradient layer 1 hands to layer 0 (K = 512,

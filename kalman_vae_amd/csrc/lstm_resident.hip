@@ -259,7 +259,9 @@ lstm128_forward_body(int T, int B, const float* __restrict__ x, const float* __r
         cst[i][1] = cv[i].y;
         put_h(1, 4 * s + i, hv[i]);
     }
-    __syncthreads();
+    // LDS only: a full barrier would also wait for the previous tile's stores to land (and
+    // for the prefetched loads), once per tile
+    lds_barrier();
     if (has_next) load_state(r0 + tile_stride);
     auto load_gx = [&](int t, GateRows& g_) { load_gx_at(r0, t, g_); };
 #else

@@ -1,0 +1,344 @@
+// ONE time step of an upper LSTM layer (hidden size 128, input = the lower layer's h, also
+// 128 wide) over very many rows, input projection included:
+//     gates = x W_ih^T + h_prev W_hh^T + b,   c = f c_prev + i g,   h = o tanh(c)
+// (one step of torch.nn.LSTM's second layer, kvae/dynamics_parameter_network.py:46-58, as the
+// masked filter calls it once per time step: kvae/state_space_model.py:279-282).
+//
+// Run as two launches (a row-streaming product that writes the (rows, 512) input projection,
+// then the recurrent kernel that reads it back) the step moves 6.5 KB per row through HBM, 4 KB
+// of it the projection's round trip.  Both matrices do not fit one compute unit's registers
+// (2 x 256 KB as bf16 hi + lo halves), but a single step has no recurrence inside the
+// launch, so the hidden units can be cut in two: a workgroup owns 64 units, keeps the
+// 256 x 256 slice [W_ih^T ; W_hh^T] of their four gates in registers (256 per lane, B
+// operands of v_mfma_f32_16x16x32_bf16, split into hi and lo bf16 halves) and works
+// through 16-row tiles of [x | h_prev]: global -> registers -> split -> LDS (double
+// buffered, the next tile in flight during this tile's matrix instructions) -> A
+// operands, 96 matrix instructions per wavefront and tile, then the cell update in the
+// epilogue.  3.5 KB per row (x and h_prev are read by both halves; the two workgroups of a
+// tile sit on one XCD and walk the tiles in the same order, so the second read comes
+// from L2).  Products are a_hi b_hi + a_lo b_hi + a_hi b_lo with fp32 accumulation, as in
+// lstm_resident.hip.  Wavefront w of half hh owns units 64 hh + 16 w .. + 15, lane (cc, s)
+// unit 64 hh + 16 w + cc of rows 4s .. 4s+3: its four accumulators are that unit's i, f, g, o.
+//
+// The same kernel steps the LOWER layer (template P = its input width, 1 or 2): the narrow
+// input is projected with plain multiply-adds, only h_prev W_hh^T runs on the matrix
+// instruction (K = 128), so one workgroup holds all of the layer's matrix: wavefront w owns
+// units 32 w .. 32 w + 31, lane (cc, s) the adjacent units 32 w + 2 cc, + 1 (8-byte stores),
+// 2 KB per row.  The many-tiles form of the recurrent kernel (lstm_resident.hip) keeps one
+// tile in flight and runs such a step at 2.1 TB/s; this one at the rate of the upper layer.
+#include <hip/hip_runtime.h>
+
+#include "../../include/kvae_kalman.h"
+#include "lstm_common.h"
+
+namespace kvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void sf_split_pair(float x, float y, unsigned& hi, unsigned& lo) {
+    const f32x2v v = {x, y};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2v r = {x - __builtin_bit_cast(float, hi << 16),
+                      y - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ void sf_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sf_split_pair(x[2 * j], x[2 * j + 1], h[j], l[j]);
+    const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+    hi = __builtin_bit_cast(bf16x8, hv);
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+constexpr int SF_H = 128, SF_G4 = 512;
+constexpr int SF_K = 2 * SF_H;            // [x | h_prev]
+
+// P == 0 (upper layer): grid = 16 * groups, block = 256; x (M,128), Wx = W_ih^T (128,512).
+// P in 1..2 (lower layer): grid = walkers, block = 256; x (M,P), Wx = W_ih (512,P) as stored.
+// h_prev, c_prev, h_out, c_out: (M,128); h_prev / c_prev may be null (zero state).
+// WhhT: (128,512) = the stored (4H,H) matrix transposed; bias (512) = b_ih + b_hh.
+// FULL: M is a multiple of 16 (no row predicates); STATE: h_prev / c_prev are given.
+template <int P, bool FULL, bool STATE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __restrict__ Wx,
+                          const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                          const float* __restrict__ WhhT, const float* __restrict__ bias,
+                          float* __restrict__ h_out, float* __restrict__ c_out) {
+    constexpr int UB = P > 0 ? 2 : 1;            // units per lane
+    constexpr int KD = P > 0 ? SF_H : SF_K;      // depth of the matrix-instruction product
+    constexpr int KK = KD / 32;
+    constexpr int LD = KD + 8;                   // bf16 per LDS row: rows 4 banks apart
+    constexpr int V4 = KD * 16 / (256 * 4);      // float4 loads per lane per tile
+    struct Tile {
+        __bf16 hi[16 * LD], lo[16 * LD];
+    };
+    __shared__ __attribute__((aligned(16))) Tile xt[2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cc = lane & 15, s = lane >> 4;
+    // upper layer: consecutive workgroup ids go round the 8 XCDs, and the two halves of a tile
+    // walker share one
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int half = P > 0 ? 0 : (j & 1);
+    const long walker = P > 0 ? bid : (long)(j >> 1) * 8 + xcd;
+    const long walkers = P > 0 ? gridDim.x : gridDim.x / 2;
+    const int unit0 = P > 0 ? 32 * wave + 2 * cc : 64 * half + 16 * wave + cc;   // + ub
+
+    // w*[ub][g][kk] multiplies the tile's column 32 kk + 8 s + . into gate g of unit0 + ub
+    bf16x8 whi[UB][4][KK], wlo[UB][4][KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const float* W = (P == 0 && kk < 4) ? Wx : WhhT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    v[jj] = W[(long)(32 * (kk & 3) + 8 * s + jj) * SF_G4 + g * SF_H + unit0 + ub];
+                sf_split8(v, whi[ub][g][kk], wlo[ub][g][kk]);
+            }
+        }
+    }
+    float bs[UB][4], wx[UB][4][P > 0 ? P : 1];
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bs[ub][g] = bias[g * SF_H + unit0 + ub];
+#pragma unroll
+            for (int q = 0; q < P; ++q) wx[ub][g][q] = Wx[(long)(g * SF_H + unit0 + ub) * P + q];
+        }
+    }
+
+    const long ntiles = (M + 15) / 16;
+    // Two tiles ahead of the one being multiplied are in flight in registers (s1: tile k+1,
+    // s2: tile k+2).  The loop body has no branch (loads past the walker's last tile re-read
+    // that tile, FULL drops the row predicates), so the compiler counts outstanding memory
+    // operations exactly; with branches it waits for ALL of them -- the stores of the tile
+    // just finished included -- before it touches a prefetched tile, once per tile.
+    struct Stage {
+        f32x4v xr[V4];
+        float cp[4][UB], xv[4][P > 0 ? P : 1];
+    };
+    auto load_tile = [&](long tile, Stage& d) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            const int flat = 4 * (tid + 256 * i), row = flat / KD, col = flat % KD;
+            const long grow = tile * 16 + row;
+            const float* src = (P == 0 && col < SF_H) ? x : h_prev;
+            const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            d.xr[i] = ((FULL || grow < M) && (src != nullptr))
+                          ? *reinterpret_cast<const f32x4v*>(src + grow * SF_H + (col & (SF_H - 1)))
+                          : z;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long grow = tile * 16 + 4 * s + r;
+            const bool ok = FULL || grow < M;
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub)
+                d.cp[r][ub] = (ok && STATE) ? c_prev[grow * SF_H + unit0 + ub] : 0.f;
+#pragma unroll
+            for (int q = 0; q < P; ++q) d.xv[r][q] = ok ? x[grow * P + q] : 0.f;
+        }
+    };
+    auto put_tile = [&](int buf, const Stage& d) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            const int flat = 4 * (tid + 256 * i), row = flat / KD, col = flat % KD;
+            u32x2 h, l;
+            unsigned a, b;
+            sf_split_pair(d.xr[i][0], d.xr[i][1], a, b);
+            h[0] = a; l[0] = b;
+            sf_split_pair(d.xr[i][2], d.xr[i][3], a, b);
+            h[1] = a; l[1] = b;
+            *reinterpret_cast<u32x2*>(&xt[buf].hi[row * LD + col]) = h;
+            *reinterpret_cast<u32x2*>(&xt[buf].lo[row * LD + col]) = l;
+        }
+    };
+
+    // tile k of this walker is tile index walker + k * walkers
+    const long mine = walker < ntiles ? (ntiles - walker + walkers - 1) / walkers : 0;
+    if (mine == 0) return;                       // the whole workgroup
+    const long last = walker + (mine - 1) * walkers;
+    auto tile_of = [&](long k) { return k < mine ? walker + k * walkers : last; };
+    Stage s0, s1, s2;
+    load_tile(tile_of(0), s0);
+    load_tile(tile_of(1), s1);
+    load_tile(tile_of(2), s2);
+    float cnow[4][UB], xnow[4][P > 0 ? P : 1];
+    auto take = [&](const Stage& d) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) cnow[r][ub] = d.cp[r][ub];
+#pragma unroll
+            for (int q = 0; q < P; ++q) xnow[r][q] = d.xv[r][q];
+        }
+    };
+    put_tile(0, s0);
+    take(s0);
+    __syncthreads();
+    int buf = 0;
+    for (long k = 0; k < mine; ++k) {
+        const long tile = walker + k * walkers;
+        f32x4v acc[UB][4];
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = bs[ub][g];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) a += xnow[r][q] * wx[ub][g][q];
+                    acc[ub][g][r] = a;
+                }
+            }
+        }
+        float cthis[4][UB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) cthis[r][ub] = cnow[r][ub];
+        }
+        // tile k+1 (in s1 since the previous iteration) into the other LDS buffer, s2 moves
+        // up, tile k+3 is requested
+        put_tile(buf ^ 1, s1);
+        take(s1);
+        s1 = s2;
+        load_tile(tile_of(k + 3), s2);
+        const int a_off = cc * LD + 8 * s;
+        bf16x8 ah[2][2], al[2][2];
+        auto read_group = [&](int grp, bf16x8 (&h_)[2], bf16x8 (&l_)[2]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                h_[q] = *reinterpret_cast<const bf16x8*>(&xt[buf].hi[a_off + 32 * (2 * grp + q)]);
+                l_[q] = *reinterpret_cast<const bf16x8*>(&xt[buf].lo[a_off + 32 * (2 * grp + q)]);
+            }
+        };
+        read_group(0, ah[0], al[0]);
+#pragma unroll
+        for (int grp = 0; grp < KK / 2; ++grp) {
+            if (grp + 1 < KK / 2) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int kk = 2 * grp + q;
+#pragma unroll
+                for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[ub][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], whi[ub][g][kk], acc[ub][g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[ub][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[grp & 1][q], whi[ub][g][kk], acc[ub][g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[ub][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], wlo[ub][g][kk], acc[ub][g], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // cell update of rows 4s .. 4s+3 for this lane's unit(s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long grow = tile * 16 + 4 * s + r;
+            float hn[UB], cn[UB];
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) {
+                const float a_i = sigmoidf_(acc[ub][0][r]), a_f = sigmoidf_(acc[ub][1][r]);
+                const float a_g = tanhf_(acc[ub][2][r]), a_o = sigmoidf_(acc[ub][3][r]);
+                cn[ub] = a_f * cthis[r][ub] + a_i * a_g;
+                hn[ub] = a_o * tanhf_(cn[ub]);
+            }
+            if (FULL || grow < M) {
+                if constexpr (UB == 2) {
+                    store_streaming(h_out + grow * SF_H + unit0, make_float2(hn[0], hn[1]));
+                    store_streaming(c_out + grow * SF_H + unit0, make_float2(cn[0], cn[1]));
+                } else {
+                    __builtin_nontemporal_store(hn[0], h_out + grow * SF_H + unit0);
+                    __builtin_nontemporal_store(cn[0], c_out + grow * SF_H + unit0);
+                }
+            }
+        }
+        // orders the writes of the next tile before its reads; the buffer written in the
+        // next iteration was last read in this one, before this barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf ^= 1;
+    }
+}
+
+}  // namespace kvae
+
+using namespace kvae;
+
+extern "C" {
+
+int kvae_lstm128_step_fused(long B, int P, const void* x, const void* Wx, const void* h_prev,
+                            const void* c_prev, const void* WhhT, const void* bias, void* h_out,
+                            void* c_out, void* stream) {
+    if (B < 1 || !x || !Wx || !WhhT || !bias || !h_out || !c_out ||
+        (h_prev == nullptr) != (c_prev == nullptr))
+        return KVAE_E_BADARG;
+    // wider inputs do not leave the registers for the tiles in flight: use kvae_lstm128_forward
+    if (P < 0 || P > 2) return KVAE_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(h_prev) | (P == 0 ? reinterpret_cast<uintptr_t>(x) : 0)) & 15)
+        return KVAE_E_BADARG;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess &&
+               hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+               n > 0) ? n : 256;
+    }
+    const long tiles = (B + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define KVAE_SF_ARGS                                                                          \
+    B, (const float*)x, (const float*)Wx, (const float*)h_prev, (const float*)c_prev,         \
+        (const float*)WhhT, (const float*)bias, (float*)h_out, (float*)c_out
+#define KVAE_SF_LAUNCH(P_, grid_)                                                             \
+    do {                                                                                      \
+        if (full && state)                                                                    \
+            hipLaunchKernelGGL((lstm128_step_fused_kernel<P_, true, true>), grid_, dim3(256), \
+                               0, s, KVAE_SF_ARGS);                                           \
+        else if (state)                                                                       \
+            hipLaunchKernelGGL((lstm128_step_fused_kernel<P_, false, true>), grid_, dim3(256), \
+                               0, s, KVAE_SF_ARGS);                                           \
+        else                                                                                  \
+            hipLaunchKernelGGL((lstm128_step_fused_kernel<P_, false, false>), grid_, dim3(256), \
+                               0, s, KVAE_SF_ARGS);                                           \
+    } while (0)
+    const bool full = B % 16 == 0, state = h_prev != nullptr;
+    if (P == 0) {
+        // tile walkers in groups of 8 (one per XCD), two workgroups (unit halves) per walker,
+        // one workgroup per compute unit
+        long groups = cus / 16;
+        if (groups < 1) groups = 1;
+        if ((tiles + 7) / 8 < groups) groups = (tiles + 7) / 8;
+        const dim3 grid((unsigned)(16 * groups));
+        KVAE_SF_LAUNCH(0, grid);
+    } else {
+        const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+        if (P == 1)
+            KVAE_SF_LAUNCH(1, grid);
+        else
+            KVAE_SF_LAUNCH(2, grid);
+    }
+#undef KVAE_SF_LAUNCH
+#undef KVAE_SF_ARGS
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -550,13 +550,30 @@ def lstm2_nograd(x, lstm, hidden=None):
         # unit), layer 1's input projection as one library GEMM in between
         stream = capi.current_stream_ptr()
         init = lambda t, l: None if t is None else t[l].data_ptr()
-        capi.check(lib.kvae_lstm128_forward(
-            T, B, P, x.data_ptr(), keep[0].data_ptr(), b0.data_ptr(), whh0t.data_ptr(), None,
-            h0.data_ptr(), c0.data_ptr(), init(h_init, 0), init(c_init, 0), 0, stream))
-        gates1 = _rows_matmul(h0.view(T * B, H), wih1t, b1, new(T * B, 4 * H))
-        capi.check(lib.kvae_lstm128_forward(
-            T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
-            c1.data_ptr(), init(h_init, 1), init(c_init, 1), 0, stream))
+        if T == 1 and x.dtype == torch.float32 and lib.kvae_lstm128_get_precision() == 1:
+            # one step over many rows: each layer as one launch with its input projection in
+            # the kernel (the upper layer's (B,512) projection never goes through memory) and
+            # several tiles of rows in flight per compute unit
+            if P <= 2:
+                capi.check(lib.kvae_lstm128_step_fused(
+                    B, P, x.data_ptr(), keep[0].data_ptr(), init(h_init, 0), init(c_init, 0),
+                    whh0t.data_ptr(), b0.data_ptr(), h0.data_ptr(), c0.data_ptr(), stream))
+            else:
+                capi.check(lib.kvae_lstm128_forward(
+                    T, B, P, x.data_ptr(), keep[0].data_ptr(), b0.data_ptr(), whh0t.data_ptr(),
+                    None, h0.data_ptr(), c0.data_ptr(), init(h_init, 0), init(c_init, 0), 0,
+                    stream))
+            capi.check(lib.kvae_lstm128_step_fused(
+                B, 0, h0.data_ptr(), wih1t.data_ptr(), init(h_init, 1), init(c_init, 1),
+                whh1t.data_ptr(), b1.data_ptr(), h1.data_ptr(), c1.data_ptr(), stream))
+        else:
+            capi.check(lib.kvae_lstm128_forward(
+                T, B, P, x.data_ptr(), keep[0].data_ptr(), b0.data_ptr(), whh0t.data_ptr(), None,
+                h0.data_ptr(), c0.data_ptr(), init(h_init, 0), init(c_init, 0), 0, stream))
+            gates1 = _rows_matmul(h0.view(T * B, H), wih1t, b1, new(T * B, 4 * H))
+            capi.check(lib.kvae_lstm128_forward(
+                T, B, 0, None, None, None, whh1t.data_ptr(), gates1.data_ptr(), h1.data_ptr(),
+                c1.data_ptr(), init(h_init, 1), init(c_init, 1), 0, stream))
         if T == 1:
             return h1, (h_n, c_n)
         return h1, (torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]]))

@@ -339,3 +339,50 @@ def test_lstm_with_head_in_one_node_matches_separate_nodes(T, B, P, K, lead):
     bad = [(n, rel_err(a, b), rel_err(a, c)) for n, a, b, c in zip(names, g1, g2, g3)
            if not (rel_err(a, b) < 2e-5 and rel_err(a, c) < 1e-4)]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("P", [0, 1, 2])
+@pytest.mark.parametrize("B,carried", [(16 * 300 + 5, True), (7, True), (16 * 2048, False),
+                                       (1, False), (16 * 129, True)])
+def test_layer_step_with_projection_in_kernel_matches_torch(B, carried, P):
+    """kvae_lstm128_step_fused (one step of a layer over many rows, input projection in the
+    kernel; the upper layer's hidden units cut over two workgroups) against one step of a
+    torch LSTM layer in float64: fewer tiles than workgroups, many tiles per workgroup, ragged
+    last tile, zero state; upper layer (P = 0, 128-wide input) and lower layer (narrow input)."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(B + P)
+    dev = torch.device("cuda:0")
+    H = 128
+    in_dim = P if P > 0 else H
+    lstm = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev)
+    x = torch.randn(1, B, in_dim, device=dev)
+    h_in, c_in = 0.5 * torch.randn(1, B, H, device=dev), 0.5 * torch.randn(1, B, H, device=dev)
+    ref64 = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev).double()
+    ref64.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+        state = (h_in.double(), c_in.double()) if carried else None
+        _, (hn, cn) = ref64(x.double(), state)
+    w_ih = lstm.weight_ih_l0.detach()
+    wx = w_ih.t().contiguous() if P == 0 else w_ih.contiguous()
+    whht = lstm.weight_hh_l0.detach().t().contiguous()
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().contiguous()
+    h = torch.full((B, H), float("nan"), device=dev)
+    c = torch.full((B, H), float("nan"), device=dev)
+    hp, cp = h_in[0].contiguous(), c_in[0].contiguous()
+    xs = x[0].contiguous()
+    rc = lib.kvae_lstm128_step_fused(B, P, xs.data_ptr(), wx.data_ptr(),
+                                     hp.data_ptr() if carried else None,
+                                     cp.data_ptr() if carried else None, whht.data_ptr(),
+                                     bias.data_ptr(), h.data_ptr(), c.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    # split products: ~1e-6 of the size of a gate sum's terms; the inputs here are N(0,1),
+    # larger than the (-1,1) outputs of a lower layer, and the maximum is over up to 4 M entries
+    assert rel_err(h, hn[0]) < 3e-5 and rel_err(c, cn[0]) < 3e-5
+    assert lib.kvae_lstm128_step_fused(B, P, xs.data_ptr(), wx.data_ptr(), hp.data_ptr(), None,
+                                       whht.data_ptr(), bias.data_ptr(), h.data_ptr(),
+                                       c.data_ptr(), None) != 0
+    assert lib.kvae_lstm128_step_fused(B, 3, xs.data_ptr(), wx.data_ptr(), None, None,
+                                       whht.data_ptr(), bias.data_ptr(), h.data_ptr(),
+                                       c.data_ptr(), None) == -2
