@@ -51,7 +51,8 @@ __device__ __forceinline__ void lds_only_barrier() {
 
 // grid = min(tiles, compute units), block = 256.  X (M,KD), W (KD,ND), bias (ND) or null,
 // Y (M,ND), all fp32 row-major.
-template <int KD, int ND>
+// FULL: M is a multiple of 16 (no row predicates).
+template <int KD, int ND, bool FULL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __restrict__ W,
                         const float* __restrict__ bias, float* __restrict__ Y) {
@@ -60,6 +61,7 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
     constexpr int LD = KD + 8;                  // bf16 per LDS row: rows 4 banks apart
     constexpr int V4 = KD * 16 / (256 * 4);     // float4 loads per lane per tile
     constexpr int GRP = KK < 4 ? KK : 2;        // k-groups whose A operands are read together
+    constexpr int DEPTH = 2;                    // tiles in flight behind the next one
     static_assert(KD * ND == 65536 && KD % 32 == 0 && ND % 64 == 0 && V4 >= 1, "shape");
     struct Tile {
         __bf16 hi[16 * LD], lo[16 * LD];
@@ -94,44 +96,55 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
     for (int j = 0; j < NB; ++j) bs[j] = bias ? bias[cbase + j] : 0.f;
 
     const long ntiles = (M + 15) / 16;
-    f32x4v xr[V4];
-    auto load_tile = [&](long tile) {
+    // Two tiles ahead of the one being multiplied are in flight in registers.  The loop body
+    // has no branch (loads past the workgroup's last tile re-read that tile, FULL drops the row
+    // predicates), so the compiler counts outstanding memory operations exactly; with branches
+    // it waits for ALL of them -- the stores of the tile just finished included -- before it
+    // touches a prefetched tile, once per tile.
+    struct Stage {
+        f32x4v xr[V4];
+    };
+    auto load_tile = [&](long tile, Stage& d) {
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
             const int flat = 4 * (tid + 256 * i), row = flat / KD, col = flat % KD;
             const long grow = tile * 16 + row;
             const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-            xr[i] = grow < M ? __builtin_nontemporal_load(
-                                   reinterpret_cast<const f32x4v*>(X + grow * KD + col))
-                             : z;
+            d.xr[i] = (FULL || grow < M) ? __builtin_nontemporal_load(
+                                               reinterpret_cast<const f32x4v*>(X + grow * KD + col))
+                                         : z;
         }
     };
-    auto put_tile = [&](int buf) {
+    auto put_tile = [&](int buf, const Stage& d) {
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
             const int flat = 4 * (tid + 256 * i), row = flat / KD, col = flat % KD;
             u32x2 h, l;
             unsigned a, b;
-            split_pair(xr[i][0], xr[i][1], a, b);
+            split_pair(d.xr[i][0], d.xr[i][1], a, b);
             h[0] = a; l[0] = b;
-            split_pair(xr[i][2], xr[i][3], a, b);
+            split_pair(d.xr[i][2], d.xr[i][3], a, b);
             h[1] = a; l[1] = b;
             *reinterpret_cast<u32x2*>(&xt[buf].hi[row * LD + col]) = h;
             *reinterpret_cast<u32x2*>(&xt[buf].lo[row * LD + col]) = l;
         }
     };
 
-    long tile = blockIdx.x;
-    if (tile < ntiles) {
-        load_tile(tile);
-        put_tile(0);
-    }
+    // tile k of this workgroup is tile index blockIdx.x + k * gridDim.x
+    const long first = blockIdx.x, stride = gridDim.x;
+    const long mine = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+    if (mine == 0) return;                       // the whole workgroup
+    const long last = first + (mine - 1) * stride;
+    auto tile_of = [&](long k) { return k < mine ? first + k * stride : last; };
+    Stage s0, s1, s2;
+    load_tile(tile_of(0), s0);
+    load_tile(tile_of(1), s1);
+    if (DEPTH > 1) load_tile(tile_of(2), s2);
+    put_tile(0, s0);
     __syncthreads();
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-        const long next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
-        if (has_next) load_tile(next);      // in flight during this tile's matrix instructions
+    for (long k = 0; k < mine; ++k) {
+        const long tile = first + k * stride;
         f32x4v acc[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -145,6 +158,15 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
             }
         };
         read_group(0, ah[0], al[0]);
+        // tile k+1 into the other LDS buffer; the stage behind it moves up and the next tile
+        // is requested
+        put_tile(buf ^ 1, s1);
+        if (DEPTH > 1) {
+            s1 = s2;
+            load_tile(tile_of(k + 3), s2);
+        } else {
+            load_tile(tile_of(k + 2), s1);
+        }
 #pragma unroll
         for (int grp = 0; grp < KK / GRP; ++grp) {
             if (grp + 1 < KK / GRP) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
@@ -167,7 +189,7 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long grow = tile * 16 + 4 * s + r;
-            if (grow < M) {
+            if (FULL || grow < M) {
                 float* yr = Y + grow * ND + cbase;
                 if constexpr (NB == 8) {
                     const f32x4v a = {acc[0][r] + bs[0], acc[1][r] + bs[1], acc[2][r] + bs[2],
@@ -183,7 +205,6 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
                 }
             }
         }
-        if (has_next) put_tile(buf ^ 1);
         // orders the writes of the next tile before its reads; the buffer written in the next
         // iteration was last read in this one, before this barrier
         lds_only_barrier();
@@ -213,14 +234,17 @@ int kvae_rowstream_matmul(long M, int K, int N, const void* X, const void* W, co
     }
     const long tiles = (M + 15) / 16;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
-    if (K == 128)
-        hipLaunchKernelGGL((rowstream_matmul_kernel<128, 512>), grid, dim3(256), 0,
-                           (hipStream_t)stream, M, (const float*)X, (const float*)W,
-                           (const float*)bias, (float*)Y);
-    else
-        hipLaunchKernelGGL((rowstream_matmul_kernel<512, 128>), grid, dim3(256), 0,
-                           (hipStream_t)stream, M, (const float*)X, (const float*)W,
-                           (const float*)bias, (float*)Y);
+#define KVAE_RS_LAUNCH(K_, N_, F_)                                                          \
+    hipLaunchKernelGGL((rowstream_matmul_kernel<K_, N_, F_>), grid, dim3(256), 0,            \
+                       (hipStream_t)stream, M, (const float*)X, (const float*)W,             \
+                       (const float*)bias, (float*)Y)
+    const bool full = M % 16 == 0;
+    if (K == 128) {
+        if (full) KVAE_RS_LAUNCH(128, 512, true); else KVAE_RS_LAUNCH(128, 512, false);
+    } else {
+        if (full) KVAE_RS_LAUNCH(512, 128, true); else KVAE_RS_LAUNCH(512, 128, false);
+    }
+#undef KVAE_RS_LAUNCH
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

@@ -59,18 +59,19 @@ constexpr int WG_GC = 512;      // columns of dG
 constexpr int WG_H = 128;       // columns of H
 constexpr int WG_AC = 128;      // columns of dG per workgroup
 constexpr int WG_TC = WG_AC + WG_H;   // columns of the combined tile: [dG slice | H]
-#ifndef WG_D
-#define WG_D 2                  // register ring depth (steps)
-#endif
 
 // grid = 8 * ceil(slabs/8) * 4, block = 512.  rows_per_slab is a multiple of 64.
-// Rows paired with dG row m are H[m - shift].  Slab s writes its (512, 128) result at
-// partial + s * partial_stride.
+// Row m of dG is paired with row m of H (the launcher applies a row offset to the
+// pointers).  Slab s writes its (512, 128) result at partial + s * partial_stride.
+// FULL: slabs * rows_per_slab == R, no row exists only in part.  The step loop has no
+// branch then (loads past the slab's last step re-read that step), so the compiler counts
+// the outstanding loads exactly and a step waits only for its own tile, not for the two
+// steps requested behind it.
+template <bool FULL>
 __global__ void __launch_bounds__(512)
 wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__ dG,
-                const float* __restrict__ Hm, long shift, float* __restrict__ partial,
+                const float* __restrict__ Hm, float* __restrict__ partial,
                 long partial_stride) {
-    constexpr int D = WG_D;
     struct Tile {
         __bf16 hi[WG_TC * WG_LDC], lo[WG_TC * WG_LDC];
     };
@@ -90,34 +91,29 @@ wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__
     // group q = lane of the combined tile; q < 32: dG, else H
     const int g = wave, q = lane;
     const bool is_a = q < 32;
-    const float* src = is_a ? dG + c0 + 4 * q : Hm + 4 * (q - 32) - shift * WG_H;
-    const long stride = is_a ? WG_GC : WG_H, first = is_a ? 0 : shift;
-    f32x4v pr[D][8];
-    auto load_step = [&](int k, f32x4v (&dst)[8]) {
+    const float* src = is_a ? dG + c0 + 4 * q : Hm + 4 * (q - 32);
+    const long stride = is_a ? WG_GC : WG_H;
+    struct Stage {
+        f32x4v v[8];
+    };
+    auto load_step = [&](int k, Stage& dst) {
         const long m0 = m_begin + (long)WG_ROWS * k + 8 * g;
-        if (m0 >= first && m0 + 8 <= R) {          // the common case: no row predicate
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                dst[jj] = *reinterpret_cast<const f32x4v*>(src + (m0 + jj) * stride);
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const long m = m0 + jj;
-                const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-                dst[jj] = (m < R && m >= first)
-                              ? *reinterpret_cast<const f32x4v*>(src + m * stride) : z;
-            }
+        for (int jj = 0; jj < 8; ++jj) {
+            const long m = m0 + jj;
+            const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            dst.v[jj] = (FULL || m < R) ? *reinterpret_cast<const f32x4v*>(src + m * stride) : z;
         }
     };
     // a column's eight 8-row pieces are stored in the order g ^ ((column / 16) & 3): the
     // 16-byte writes of a wavefront (columns 4 apart) then fall into different banks, and a
     // matrix-instruction read (16 adjacent columns, one 16-column block) sees one order
-    auto put_step = [&](int buf, const f32x4v (&v)[8]) {
+    auto put_step = [&](int buf, const Stage& st) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) x[jj] = v[jj][e];
+            for (int jj = 0; jj < 8; ++jj) x[jj] = st.v[jj][e];
             u32x4 hi, lo;
             wg_split8(x, hi, lo);
             const int col = 4 * q + e, pg = g ^ ((col >> 4) & 3);
@@ -132,57 +128,63 @@ wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (d < nks) load_step(d, pr[d]);
+    auto step_of = [&](int k) { return k < nks ? k : nks - 1; };
+    // s1, s2: the steps after the one whose tile is in LDS, in flight in registers
+    Stage s1, s2;
+    {
+        Stage s0;
+        load_step(0, s0);
+        load_step(step_of(1), s1);
+        load_step(step_of(2), s2);
+        put_step(0, s0);
     }
-    put_step(0, pr[0]);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (D < nks) load_step(D, pr[0]);
-    int buf = 0;
-    for (int ks = 0; ks < nks; ks += D) {
+    // One step: multiply the tile in LDS buffer `buf`; meanwhile `next` (step k+1, in flight
+    // since two steps ago) goes into the other buffer and is refilled with step k+3.  The two
+    // stages take the role of `next` in turn (a copy between them would wait for the younger
+    // one's loads), so the loop below is unrolled by two and an odd last step is peeled.
+    auto step = [&](int k, int buf, Stage& next) {
+        // this wavefront's operands: 8-row groups 4 kh + s of the step
+        bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int k = ks + u;
-            if (k >= nks) break;
-            // this wavefront's operands: 8-row groups 4 kh + s of the step
-            bf16x8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int blk = 4 * wm + qq;
-                const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
-                ah[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
-                al[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
-            }
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int blk = WG_AC / 16 + 4 * wn + qq;
-                const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
-                bh[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
-                bl[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
-            }
-            // stage (u+1) % D holds step k+1: into the other buffer, then refilled with step
-            // k+1+D
-            if (k + 1 < nks) put_step(buf ^ 1, pr[(u + 1) % D]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-            if (k + 1 + D < nks) load_step(k + 1 + D, pr[(u + 1) % D]);
-            // orders the writes of step k+1 before its reads; the buffer written in the next
-            // iteration is the one read in this one, before this barrier
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            buf ^= 1;
+        for (int qq = 0; qq < 4; ++qq) {
+            const int blk = 4 * wm + qq;
+            const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
+            ah[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
+            al[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
         }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int blk = WG_AC / 16 + 4 * wn + qq;
+            const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
+            bh[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
+            bl[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
+        }
+        // (after the slab's last step this writes a copy of it that nothing reads)
+        put_step(buf ^ 1, next);
+        load_step(step_of(k + 3), next);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        // orders the writes of step k+1 before its reads; the buffer written in the next
+        // step is the one read in this one, before this barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    int k = 0;
+    for (; k + 1 < nks; k += 2) {
+        step(k, 0, s1);
+        step(k + 1, 1, s2);
     }
+    if (k < nks) step(k, 0, s1);
     // the two row halves: wavefronts 4-7 hand their accumulators over through LDS (the tiles
     // are free after the last barrier above), wavefronts 0-3 add and write
     float* xch = reinterpret_cast<float*>(&tl[0]);      // 4 wavefronts x 64 values x 64 lanes
@@ -236,12 +238,21 @@ int kvae_lstm128_wgrad(long R, const void* dG, const void* H, long shift, void* 
     if ((reinterpret_cast<uintptr_t>(dG) | reinterpret_cast<uintptr_t>(H)) & 15)
         return KVAE_E_BADARG;
     const int slabs = kvae_lstm128_wgrad_slabs(R);
-    long rps = (R + slabs - 1) / slabs;
+    // rows m >= shift of dG meet rows m - shift of H: the same product without an offset on
+    // the R - shift rows that start at dG + shift * 512 (no such rows: every slab is zero)
+    const long rows = R > shift ? R - shift : 0;
+    const float* a = (const float*)dG + shift * WG_GC;
+    long rps = (rows + slabs - 1) / slabs;
     rps = (rps + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    if (rps < WG_ROWS) rps = WG_ROWS;
     const int per_xcd = (slabs + 7) / 8;
     const dim3 grid(8 * per_xcd * 4);        // (xcd, slab within xcd, column slice)
-    hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(512), 0, (hipStream_t)stream, R, rps, slabs,
-                       (const float*)dG, (const float*)H, shift, (float*)partial, partial_stride);
+    if (rps * slabs == rows)
+        hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, rows,
+                           rps, slabs, a, (const float*)H, (float*)partial, partial_stride);
+    else
+        hipLaunchKernelGGL(wgrad_tn_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, rows,
+                           rps, slabs, a, (const float*)H, (float*)partial, partial_stride);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 
