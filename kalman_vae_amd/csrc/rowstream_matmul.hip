@@ -61,7 +61,6 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
     constexpr int LD = KD + 8;                  // bf16 per LDS row: rows 4 banks apart
     constexpr int V4 = KD * 16 / (256 * 4);     // float4 loads per lane per tile
     constexpr int GRP = KK < 4 ? KK : 2;        // k-groups whose A operands are read together
-    constexpr int DEPTH = 2;                    // tiles in flight behind the next one
     static_assert(KD * ND == 65536 && KD % 32 == 0 && ND % 64 == 0 && V4 >= 1, "shape");
     struct Tile {
         __bf16 hi[16 * LD], lo[16 * LD];
@@ -136,14 +135,19 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
     if (mine == 0) return;                       // the whole workgroup
     const long last = first + (mine - 1) * stride;
     auto tile_of = [&](long k) { return k < mine ? first + k * stride : last; };
-    Stage s0, s1, s2;
-    load_tile(tile_of(0), s0);
-    load_tile(tile_of(1), s1);
-    if (DEPTH > 1) load_tile(tile_of(2), s2);
-    put_tile(0, s0);
+    // s1, s2: the tiles after the one in LDS, in flight in registers; they take the role of
+    // `next` in turn (a copy between them would wait for the younger one's loads), so the loop
+    // is unrolled by two and an odd last tile is peeled
+    Stage s1, s2;
+    {
+        Stage s0;
+        load_tile(tile_of(0), s0);
+        load_tile(tile_of(1), s1);
+        load_tile(tile_of(2), s2);
+        put_tile(0, s0);
+    }
     __syncthreads();
-    int buf = 0;
-    for (long k = 0; k < mine; ++k) {
+    auto one_tile = [&](long k, int buf, Stage& next) {
         const long tile = first + k * stride;
         f32x4v acc[NB];
 #pragma unroll
@@ -158,15 +162,10 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
             }
         };
         read_group(0, ah[0], al[0]);
-        // tile k+1 into the other LDS buffer; the stage behind it moves up and the next tile
-        // is requested
-        put_tile(buf ^ 1, s1);
-        if (DEPTH > 1) {
-            s1 = s2;
-            load_tile(tile_of(k + 3), s2);
-        } else {
-            load_tile(tile_of(k + 2), s1);
-        }
+        // tile k+1 into the other LDS buffer (after the last tile: a copy of it that nothing
+        // reads), then tile k+3 is requested into the same registers
+        put_tile(buf ^ 1, next);
+        load_tile(tile_of(k + 3), next);
 #pragma unroll
         for (int grp = 0; grp < KK / GRP; ++grp) {
             if (grp + 1 < KK / GRP) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
@@ -206,10 +205,15 @@ rowstream_matmul_kernel(long M, const float* __restrict__ X, const float* __rest
             }
         }
         // orders the writes of the next tile before its reads; the buffer written in the next
-        // iteration was last read in this one, before this barrier
+        // call was last read in this one, before this barrier
         lds_only_barrier();
-        buf ^= 1;
+    };
+    long k = 0;
+    for (; k + 1 < mine; k += 2) {
+        one_tile(k, 0, s1);
+        one_tile(k + 1, 1, s2);
     }
+    if (k < mine) one_tile(k, 0, s1);
 }
 
 }  // namespace kvae
