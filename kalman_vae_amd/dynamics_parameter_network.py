@@ -79,6 +79,20 @@ class LSTMModel(nn.Module):
         h, self.hidden = self.lstm(x, self.hidden)
         return lstm_function.softmax_head(h, self.linear, lead)
 
+    def inference_stepper(self, x):
+        """For a caller that feeds one step at a time without a gradient (the masked
+        filter): an object whose ``step(x_t (B,a_dim), out (B,K))`` equals
+        ``out.copy_(self(x_t[None])[0])`` with fewer launches and no per-step tensors, or
+        None when that form does not apply.  Call ``finish_steps`` afterwards so that the
+        module carries the state on, as after the equivalent forward calls."""
+        if not self.use_hip_recurrence:
+            return None
+        return lstm_function.LSTM2HeadStepper.make(x, self.lstm, self.linear, self.hidden)
+
+    def finish_steps(self, stepper, steps):
+        self.hidden = stepper.hidden
+        self.count += steps
+
     is_recurrent = True
 
 

@@ -640,12 +640,15 @@ def loss_supported(n, p, K, dtype):
 
 
 @torch.no_grad()
-def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a=None, L_R=None):
+def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a=None, L_R=None,
+                       out=None):
     """One step of the masked filter's imputation for every sequence in one launch
     (kvae/state_space_model.py:232-277): returns a_w (B,p) = mask a + (1 - mask) C(w) z,
     z = A(w) m_pred (+ L_Q eps_z) (+ L_R eps_a on the observation), or None when no
     kernel is compiled for these dimensions (the caller then uses torch operations).
-    Values only: the step-by-step filter calls it when no gradient is recorded."""
+    ``out``: a contiguous (B,p) tensor to write a_w into (a slice of the caller's
+    (T,B,p) result).  Values only: the step-by-step filter calls it when no gradient is
+    recorded."""
     capi.require_gpu(w, A_K, C_K, m_pred, a, mask)
     B, K = w.shape
     n, p = m_pred.shape[1], a.shape[1]
@@ -656,16 +659,48 @@ def impute_observation(w, A_K, C_K, m_pred, a, mask, eps_z=None, L_Q=None, eps_a
         a_w = impute_observation(e.weights(w), e.bases_A(A_K), e.bases_C(C_K), e.vec_n(m_pred),
                                  e.vec_p(a), mask, e.vec_n(eps_z), e.cov_n(L_Q), e.vec_p(eps_a),
                                  e.cov_p(L_R))
-        return None if a_w is None else e.cut_p(a_w)
+        if a_w is None:
+            return None
+        return e.cut_p(a_w) if out is None else out.copy_(e.cut_p(a_w))
     dims = capi.Dims(1, B, n, p, K, code, 1, 0)
     tensors = [_c(t) for t in (w, A_K, C_K, m_pred, a, mask, eps_z, L_Q, eps_a, L_R)]
-    a_w = torch.empty(B, p, dtype=a.dtype, device=a.device)
+    if out is not None and not (out.is_contiguous() and out.shape == (B, p) and out.dtype == a.dtype):
+        raise ValueError("impute_observation: out must be a contiguous (B, a_dim) tensor of a's dtype")
+    a_w = torch.empty(B, p, dtype=a.dtype, device=a.device) if out is None else out
     rc = capi.load().kvae_impute_observation(C.byref(dims), *(capi.ptr(t) for t in tensors),
                                              a_w.data_ptr(), capi.current_stream_ptr())
     if rc == -2:      # KVAE_E_UNSUPPORTED
         return None
     capi.check(rc)
     return a_w
+
+
+@torch.no_grad()
+def filter_step_into(a_t, alpha2, mask_t, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn, As2, Cs2,
+                     symmetrize=True):
+    """One step of the filter (kvae_filter_forward with T = 1, per-sequence carry) that
+    writes into the caller's tensors: a_t (1,B,p), alpha2 (2,B,K) = the weights of this
+    step and the next, mask_t (1,B) or None, m_in (B,n), P_in (B,n,n); results m, mn
+    (1,B,n), P, Pn (1,B,n,n), As2 (2,B,n,n), Cs2 (2,B,p,n) - contiguous slices of (T, ...)
+    buffers, so a step-by-step caller never stacks per-step tensors.  Values only.  The
+    dimensions must have a kernel of their own (``embedding_dims(n, p, K) == (n, p, K)``)."""
+    tensors = (a_t, alpha2, mask_t, A_K, C_K, Q, R, m_in, P_in, m, P, mn, Pn, As2, Cs2)
+    capi.require_gpu(*tensors)
+    if not all(t is None or t.is_contiguous() for t in tensors):
+        raise ValueError("filter_step_into: every operand must be contiguous")
+    B, p = a_t.shape[1:]
+    K, n = A_K.shape[0], A_K.shape[1]
+    if (alpha2.shape != (2, B, K) or m_in.shape != (B, n) or P_in.shape != (B, n, n)
+            or m.shape != (1, B, n) or P.shape != (1, B, n, n) or mn.shape != (1, B, n)
+            or Pn.shape != (1, B, n, n) or As2.shape != (2, B, n, n) or Cs2.shape != (2, B, p, n)):
+        raise ValueError("filter_step_into: operand shapes do not match (B, n, p, K)")
+    dims = _dims(1, B, n, p, K, a_t.dtype, symmetrize, 0)
+    io = capi.fill(capi.FilterFwd(), a=a_t, alpha=alpha2, mask=mask_t, A_K=A_K, C_K=C_K, Q=Q, R=R,
+                   m_in=m_in, P_in=P_in, carry_per_sequence=1, mean_filt=m, cov_filt=P,
+                   mean_pred=mn, cov_pred=Pn, mat_As=As2, mat_Cs=Cs2,
+                   status=status_word(a_t.device))
+    capi.check(capi.load().kvae_filter_forward(C.byref(dims), C.byref(io),
+                                               capi.current_stream_ptr()))
 
 
 _impute_kernel_exists = {}

@@ -586,6 +586,68 @@ def lstm2_nograd(x, lstm, hidden=None):
     return h1, (torch.stack([h0[-1], h1[-1]]), torch.stack([c0[-1], c1[-1]]))
 
 
+class LSTM2HeadStepper:
+    """softmax(linear(lstm(x_t))) one time step at a time from a carried state, for the
+    step-by-step masked filter when no gradient is recorded (kvae/state_space_model.py:
+    279-282 calls the network once per step): the weight operands are prepared once, the
+    carried (h, c) alternate between two buffers, and a step is three launches (lower
+    layer, upper layer, head) that write the weights into the caller's tensor.
+    ``LSTM2HeadStepper.make`` returns None when this form does not apply."""
+
+    @staticmethod
+    def make(x, lstm, linear, hidden=None):
+        """x: one step's input (B, P), float32 on a GPU."""
+        if not (RESIDENT and x.dim() == 2 and not torch.is_grad_enabled()
+                and persistent_supported(x.unsqueeze(0), lstm) and x.shape[1] <= 2
+                and x.dtype == torch.float32 and head_supported(x.new_empty(1, 128), linear)
+                and capi.load().kvae_lstm128_get_precision() == 1):
+            return None
+        return LSTM2HeadStepper(x, lstm, linear, hidden)
+
+    def __init__(self, x, lstm, linear, hidden):
+        H = 128
+        self.B, self.P, self.K = x.shape[0], x.shape[1], linear.out_features
+        w = lambda n: getattr(lstm, n).detach()
+        self.whh0t, self.wih1t, self.whh1t, self.b0, self.b1 = _lstm2_operands(
+            w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"),
+            w("weight_hh_l1"), w("bias_ih_l1"), w("bias_hh_l1"))
+        self.wih0 = w("weight_ih_l0").contiguous()
+        self.Wc, self.bc = linear.weight.detach().contiguous(), linear.bias.detach().contiguous()
+        new = lambda: torch.empty(2, self.B, H, dtype=x.dtype, device=x.device)
+        self.state = [(new(), new()), (new(), new())]
+        self.now = None          # index of the buffer pair that holds the carried state
+        if hidden is not None:
+            self.state[0][0].copy_(hidden[0])
+            self.state[0][1].copy_(hidden[1])
+            self.now = 0
+
+    @torch.no_grad()
+    def step(self, x, out):
+        """x (B,P) -> out (B,K), both contiguous; advances the carried state."""
+        if not (x.is_contiguous() and out.is_contiguous() and x.shape == (self.B, self.P)
+                and out.shape == (self.B, self.K) and x.dtype == out.dtype == torch.float32):
+            raise ValueError("LSTM2HeadStepper.step: x (B,P) and out (B,K) must be contiguous float32")
+        lib, stream = capi.load(), capi.current_stream_ptr()
+        nxt = 0 if self.now is None else self.now ^ 1
+        h, c = self.state[nxt]
+        prev = lambda l, i: None if self.now is None else self.state[self.now][i][l].data_ptr()
+        capi.check(lib.kvae_lstm128_step_fused(
+            self.B, self.P, x.data_ptr(), self.wih0.data_ptr(), prev(0, 0), prev(0, 1),
+            self.whh0t.data_ptr(), self.b0.data_ptr(), h[0].data_ptr(), c[0].data_ptr(), stream))
+        capi.check(lib.kvae_lstm128_step_fused(
+            self.B, 0, h[0].data_ptr(), self.wih1t.data_ptr(), prev(1, 0), prev(1, 1),
+            self.whh1t.data_ptr(), self.b1.data_ptr(), h[1].data_ptr(), c[1].data_ptr(), stream))
+        capi.check(lib.kvae_softmax_head_forward(
+            self.B, 128, self.K, h[1].data_ptr(), self.Wc.data_ptr(), self.bc.data_ptr(),
+            out.data_ptr(), 0, stream))
+        self.now = nxt
+
+    @property
+    def hidden(self):
+        """(h_n, c_n), each (2,B,H), after the steps so far; None before the first."""
+        return None if self.now is None else self.state[self.now]
+
+
 def fused_lstm(x, lstm):
     """Run ``lstm`` (a torch.nn.LSTM, unidirectional, sequence-first) on x with
     zero initial state through the HIP recurrence.  Returns (output, (h_n, c_n))."""

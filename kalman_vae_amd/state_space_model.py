@@ -358,6 +358,13 @@ class StateSpaceModel(nn.Module):
         compiled for these dimensions."""
         T, B = as_.shape[:2]
         A_K, C_K, Q, R = self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R
+        make_stepper = getattr(self.weight_model, "inference_stepper", None)
+        if make_stepper is not None and F.embedding_dims(
+                self.z_dim, self.a_dim, self.K, as_.dtype) == (self.z_dim, self.a_dim, self.K):
+            stepper = make_stepper(as_[0])
+            if stepper is not None:
+                return self._filter_masked_stepper(as_, mask, state_noise, obs_noise, symmetrize,
+                                                   w, m_pred, P_pred, L_Q, L_R, stepper)
         out = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C", "aw", "w")}
         As2 = Cs2 = None
         for t in range(T):
@@ -379,6 +386,35 @@ class StateSpaceModel(nn.Module):
         out["C"].append(Cs2[1])
         st = {k: torch.stack(v) for k, v in out.items()}
         return st["m"], st["P"], st["mn"], st["Pn"], st["A"], st["C"], st["aw"], st["w"]
+
+    def _filter_masked_stepper(self, as_, mask, state_noise, obs_noise, symmetrize, w, m_pred,
+                               P_pred, L_Q, L_R, stepper):
+        """_filter_masked_inference with a weight network that steps into the caller's
+        tensors: every per-step result is written into its slice of the (T, ...) tensor
+        that is returned (three network launches, the imputation and the one-step filter
+        per time step; no per-step tensors, no stacking)."""
+        T, B = as_.shape[:2]
+        n, p, K = self.z_dim, self.a_dim, self.K
+        new = lambda *s: torch.empty(s, dtype=as_.dtype, device=as_.device)
+        c = lambda t: t.contiguous()
+        A_K, C_K, Q, R = c(self.mat_A_K), c(self.mat_C_K), c(self.mat_Q), c(self.mat_R)
+        as_, mask = c(as_), c(mask)
+        m, P, mn, Pn = new(T, B, n), new(T, B, n, n), new(T, B, n), new(T, B, n, n)
+        As, Cs, aw, ws = new(T + 1, B, n, n), new(T + 1, B, p, n), new(T, B, p), new(T + 1, B, K)
+        ws[0].copy_(w)
+        for t in range(T):
+            eps_z = self._draw((B, n), as_) if state_noise else None
+            eps_a = self._draw((B, p), as_) if obs_noise else None
+            F.impute_observation(ws[t], A_K, C_K, m_pred, as_[t], mask[t], eps_z, L_Q, eps_a, L_R,
+                                 out=aw[t])
+            stepper.step(aw[t], ws[t + 1])
+            # writes A_t, C_t and A_{t+1}, C_{t+1}; the next step writes the latter again
+            F.filter_step_into(as_[t:t + 1], ws[t:t + 2], mask[t:t + 1], A_K, C_K, Q, R, m_pred,
+                               P_pred, m[t:t + 1], P[t:t + 1], mn[t:t + 1], Pn[t:t + 1],
+                               As[t:t + 2], Cs[t:t + 2], symmetrize=symmetrize)
+            m_pred, P_pred = mn[t], Pn[t]
+        self.weight_model.finish_steps(stepper, T)
+        return m, P, mn, Pn, As, Cs, aw, ws[:T]
 
     def _filter_draws(self, as_, state_noise, obs_noise):
         """(eps_z (T,B,n), eps_a (T,B,p)) of the masked filter's imputation, drawn in the

@@ -338,6 +338,59 @@ def test_masked_inference_path_equals_autograd_path(net, dtype, tol, in_kernel, 
         assert rel_err(x, y.detach()) < tol
 
 
+@pytest.mark.parametrize("mode", ["mean", "sample"])
+@pytest.mark.parametrize("B", [70, 256])
+def test_masked_inference_with_stepping_network_equals_per_step_tensors(mode, B, monkeypatch):
+    """With the default LSTM network (two layers of 128 units, float32) the masked filter
+    without a gradient lets the network step into slices of the returned tensors (three
+    launches per step, nothing stacked).  Same kernels on the same inputs as the form that
+    calls the module once per step and stacks: all eight outputs bit-identical, and the
+    module carries the same state on."""
+    import kalman_vae_amd.state_space_model as sm
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    from kalman_vae_amd.lstm_function import LSTM2HeadStepper
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    T = 7
+    ssm = StateSpaceModel(a_dim=2, z_dim=4, K=3, dynamics_parameter_network="lstm").to(dev).eval()
+    a = 0.5 * torch.randn(T, B, 2, device=dev)
+    mask = (torch.rand(T, B, device=dev) < 0.6).float()
+    mask[0] = 1.0
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition=mode, observation=mode)
+    made = []
+    orig_make = LSTM2HeadStepper.make
+    monkeypatch.setattr(LSTM2HeadStepper, "make",
+                        staticmethod(lambda *x, **k: made.append(orig_make(*x, **k)) or made[-1]))
+    draws, orig = [], sm._standard_normal
+
+    def record(shape, dtype, device):
+        draws.append(orig(shape, dtype=dtype, device=device))
+        return draws[-1]
+
+    monkeypatch.setattr(sm, "_standard_normal", record)
+    with torch.no_grad():
+        fast = ssm.kalman_filter(a, sc, observation_mask=mask)
+    assert len(made) == 1 and made[0] is not None
+    state_fast = [t.clone() for t in ssm.weight_model.hidden]
+    pos = [0]
+
+    def replay(shape, dtype, device):
+        pos[0] += 1
+        return draws[pos[0] - 1]
+
+    monkeypatch.setattr(sm, "_standard_normal", replay)
+    ssm.weight_model.inference_stepper = lambda x: None
+    with torch.no_grad():
+        slow = ssm.kalman_filter(a, sc, observation_mask=mask)
+    assert pos[0] == len(draws) and len(made) == 1
+    for x, y in zip(fast, slow):
+        assert x.shape == y.shape and torch.equal(x, y)
+    for x, y in zip(state_fast, ssm.weight_model.hidden):
+        assert torch.equal(x, y)
+    import kalman_vae_amd.functions as Fn
+    assert Fn.read_status(dev) == 0
+
+
 def test_module_large_state_backward_runs_the_register_tile_kernel():
     """The module's training path at a large state dimension (fp32, z_dim=32): the filter
     backward must run the register-tile kernel (it needs the mixed per-step matrices the
