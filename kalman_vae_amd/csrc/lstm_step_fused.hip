@@ -26,6 +26,12 @@
 // units 32 w .. 32 w + 31, lane (cc, s) the adjacent units 32 w + 2 cc, + 1 (8-byte stores),
 // 2 KB per row.  The many-tiles form of the recurrent kernel (lstm_resident.hip) keeps one
 // tile in flight and runs such a step at 2.1 TB/s; this one at the rate of the upper layer.
+//
+// What bounds a step (262144 rows, MI355X): the matrix instructions.  With half of them
+// removed the upper layer takes 166 instead of 255 us and the lower layer 127 instead of
+// 167 us; without the stores 239 / 144 us, without the exp / rcp chains of the cell update
+// 227 / 150 us.  96 instructions per wavefront and tile come to about 14 ns each: the chip
+// holds its clock near 1.6 GHz under this load, where the instruction's 16 cycles are 10 ns.
 #include <hip/hip_runtime.h>
 
 #include "../../include/kvae_kalman.h"
@@ -131,9 +137,11 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
         for (int i = 0; i < V4; ++i) {
             const int flat = 4 * (tid + 256 * i), row = flat / KD, col = flat % KD;
             const long grow = tile * 16 + row;
-            const float* src = (P == 0 && col < SF_H) ? x : h_prev;
+            const bool from_x = P == 0 && col < SF_H;
+            const float* src = from_x ? x : h_prev;
             const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-            d.xr[i] = ((FULL || grow < M) && (src != nullptr))
+            // (no test of the pointer itself: that would be a branch in the tile loop)
+            d.xr[i] = ((FULL || grow < M) && (from_x || STATE))
                           ? *reinterpret_cast<const f32x4v*>(src + grow * SF_H + (col & (SF_H - 1)))
                           : z;
         }
@@ -185,10 +193,13 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
     put_tile(0, s0);
     take(s0);
     __syncthreads();
-    int buf = 0;
-    for (long k = 0; k < mine; ++k) {
-        const long tile = walker + k * walkers;
-        f32x4v acc[UB][4];
+    // The cell update of a tile (exp / rcp chains, stores) does not depend on the matrix
+    // instructions of the NEXT tile, and with one wavefront per SIMD nothing else could fill
+    // the matrix core's shadow: iteration k multiplies tile k and, between its groups of
+    // matrix instructions, finishes tile k-1 from `accp` / `cprev`.
+    f32x4v acc[UB][4], accp[UB][4];
+    float cthis[4][UB], cprev[4][UB];
+    auto begin_tile = [&]() {
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
 #pragma unroll
@@ -202,19 +213,58 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
                 }
             }
         }
-        float cthis[4][UB];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int ub = 0; ub < UB; ++ub) cthis[r][ub] = cnow[r][ub];
         }
-        // tile k+1 (in s1 since the previous iteration) into the other LDS buffer, s2 moves
-        // up, tile k+3 is requested
+    };
+    // tile k+1 (in s1 since the previous iteration) into the other LDS buffer, s2 moves up,
+    // tile k+3 is requested
+    auto advance = [&](long k, int buf) {
         put_tile(buf ^ 1, s1);
         take(s1);
         s1 = s2;
         load_tile(tile_of(k + 3), s2);
-        const int a_off = cc * LD + 8 * s;
+    };
+    auto retire = [&]() {
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accp[ub][g] = acc[ub][g];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) cprev[r][ub] = cthis[r][ub];
+        }
+    };
+    // cell update of row 4s + r of `tile` for this lane's unit(s), from accp / cprev
+    auto cell_row = [&](int r, long tile) {
+        const long grow = tile * 16 + 4 * s + r;
+        float hn[UB], cn[UB];
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+            const float a_i = sigmoidf_(accp[ub][0][r]), a_f = sigmoidf_(accp[ub][1][r]);
+            const float a_g = tanhf_(accp[ub][2][r]), a_o = sigmoidf_(accp[ub][3][r]);
+            cn[ub] = a_f * cprev[r][ub] + a_i * a_g;
+            hn[ub] = a_o * tanhf_(cn[ub]);
+        }
+        if (FULL || grow < M) {
+            if constexpr (UB == 2) {
+                store_streaming(h_out + grow * SF_H + unit0, make_float2(hn[0], hn[1]));
+                store_streaming(c_out + grow * SF_H + unit0, make_float2(cn[0], cn[1]));
+            } else {
+                __builtin_nontemporal_store(hn[0], h_out + grow * SF_H + unit0);
+                __builtin_nontemporal_store(cn[0], c_out + grow * SF_H + unit0);
+            }
+        }
+    };
+    constexpr int GROUPS = KK / 2, ROWS_PER_GROUP = 4 / GROUPS;
+    const int a_off = cc * LD + 8 * s;
+    // the matrix instructions of the tile in LDS buffer `buf`, in GROUPS groups; between(grp)
+    // is issued with group grp
+    auto products = [&](int buf, auto&& between) {
         bf16x8 ah[2][2], al[2][2];
         auto read_group = [&](int grp, bf16x8 (&h_)[2], bf16x8 (&l_)[2]) {
 #pragma unroll
@@ -225,8 +275,8 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
         };
         read_group(0, ah[0], al[0]);
 #pragma unroll
-        for (int grp = 0; grp < KK / 2; ++grp) {
-            if (grp + 1 < KK / 2) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
+        for (int grp = 0; grp < GROUPS; ++grp) {
+            if (grp + 1 < GROUPS) read_group(grp + 1, ah[(grp + 1) & 1], al[(grp + 1) & 1]);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int kk = 2 * grp + q;
@@ -249,35 +299,33 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
                         acc[ub][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[grp & 1][q], wlo[ub][g][kk], acc[ub][g], 0, 0, 0);
                 }
             }
+            between(grp);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // cell update of rows 4s .. 4s+3 for this lane's unit(s)
+    };
+    // tile 0: nothing to finish yet
+    begin_tile();
+    advance(0, 0);
+    products(0, [](int) {});
+    // (orders the LDS writes of the next tile before its reads; the buffer written in the
+    // next iteration was last read in this one, before this barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    retire();
+    int buf = 1;
+    for (long k = 1; k < mine; ++k) {
+        const long done = walker + (k - 1) * walkers;
+        begin_tile();
+        advance(k, buf);
+        products(buf, [&](int grp) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long grow = tile * 16 + 4 * s + r;
-            float hn[UB], cn[UB];
-#pragma unroll
-            for (int ub = 0; ub < UB; ++ub) {
-                const float a_i = sigmoidf_(acc[ub][0][r]), a_f = sigmoidf_(acc[ub][1][r]);
-                const float a_g = tanhf_(acc[ub][2][r]), a_o = sigmoidf_(acc[ub][3][r]);
-                cn[ub] = a_f * cthis[r][ub] + a_i * a_g;
-                hn[ub] = a_o * tanhf_(cn[ub]);
-            }
-            if (FULL || grow < M) {
-                if constexpr (UB == 2) {
-                    store_streaming(h_out + grow * SF_H + unit0, make_float2(hn[0], hn[1]));
-                    store_streaming(c_out + grow * SF_H + unit0, make_float2(cn[0], cn[1]));
-                } else {
-                    __builtin_nontemporal_store(hn[0], h_out + grow * SF_H + unit0);
-                    __builtin_nontemporal_store(cn[0], c_out + grow * SF_H + unit0);
-                }
-            }
-        }
-        // orders the writes of the next tile before its reads; the buffer written in the
-        // next iteration was last read in this one, before this barrier
+            for (int rr = 0; rr < ROWS_PER_GROUP; ++rr) cell_row(ROWS_PER_GROUP * grp + rr, done);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        retire();
         buf ^= 1;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cell_row(r, last);
 }
 
 }  // namespace kvae
