@@ -44,6 +44,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
 VALU_FP32_PEAK_TF = 157.3   # MI355X vector fp32 spec peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix-instruction peak
 
 
 def bouncing_ball_observations(T, B, p, device, seed):
@@ -602,18 +603,79 @@ def run_imputation(args, rank, world, dev, rehearsal):
                 dom += " stage of one chunk"
                 res["kernels"] = {"masked_filter": {"us": tf * 1e6, "GBps": fb / tf / 1e9},
                                   "smoother": {"us": ts * 1e6, "GBps": sb / ts / 1e9}}
-        traffic = None
+        traffic, table = None, {}
         try:      # HBM bytes per launch counted by the PMC passes committed under profiles/
             with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as fh:
-                traffic = json.load(fh).get(f"T{T}_B{chunk}_n{n}_p{p}_K{K}", {}).get(
-                    "filter_smooth_fused" if fused and args.net == "mlp" else "")
+                table = json.load(fh)
+            traffic = table.get(f"T{T}_B{chunk}_n{n}_p{p}_K{K}", {}).get(
+                "filter_smooth_fused" if fused and args.net == "mlp" else "")
         except OSError:
             pass
         res["roofline"] = {"kernel": dom, "bound": "hbm",
                            "achieved": by / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": by / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": by, "avg_launch_us": sec * 1e6}
+        step = time_lstm_step_kernels(ssm, chunk) if args.net == "lstm" else None
+        if step is not None:
+            # with the LSTM network the workload is T steps of its two layers per chunk, one
+            # launch per layer and step; the upper layer's launch is the dominant kernel
+            res["kernels"].update(step)
+            up = step["lstm_step_upper_layer"]
+            res["kalman_roofline"] = res["roofline"]
+            res["roofline"] = {
+                "kernel": "lstm128_step_fused_kernel<0> (upper LSTM layer, one time step of one "
+                          "chunk, input projection in the kernel)",
+                "bound": "mfma", "achieved": up["TFLOPs_bf16"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": up["TFLOPs_bf16"] / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": table.get(f"lstm_step_B{chunk}", {}).get("upper_layer"),
+                "flops_per_launch": up["flops_per_launch"], "avg_launch_us": up["us"],
+                "hbm_GBps": up["GBps"],
+                "share_of_step": up["us"] * 1e-6 * T * n_chunks / (elapsed / args.steps),
+                "note": "three bf16 matrix instructions per fp32 product (hi/lo split), counted "
+                        "as executed; 2.5 KB per row through HBM"}
     return res
+
+
+def time_lstm_step_kernels(ssm, rows, iters=10):
+    """HIP-event durations of the two launches that step the default LSTM network (two layers
+    of 128 units) once over ``rows`` sequences, as the masked filter issues them per time step;
+    None for any other network."""
+    lstm = getattr(ssm.weight_model, "lstm", None)
+    if lstm is None or lstm.num_layers != 2 or lstm.hidden_size != 128 or lstm.input_size > 2:
+        return None
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd.lstm_function import _lstm2_operands
+    lib, H, P = capi.load(), 128, lstm.input_size
+    dev = lstm.weight_hh_l0.device
+    w = lambda name: getattr(lstm, name).detach()
+    whh0t, wih1t, whh1t, b0, b1 = _lstm2_operands(
+        w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
+        w("bias_ih_l1"), w("bias_hh_l1"))
+    wih0 = w("weight_ih_l0").contiguous()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    x, hp, cp = rnd(rows, P), rnd(2, rows, H), rnd(2, rows, H)
+    h, c = torch.empty(2, rows, H, device=dev), torch.empty(2, rows, H, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def lower():
+        capi.check(lib.kvae_lstm128_step_fused(
+            rows, P, x.data_ptr(), wih0.data_ptr(), hp[0].data_ptr(), cp[0].data_ptr(),
+            whh0t.data_ptr(), b0.data_ptr(), h[0].data_ptr(), c[0].data_ptr(), st))
+
+    def upper():
+        capi.check(lib.kvae_lstm128_step_fused(
+            rows, 0, h[0].data_ptr(), wih1t.data_ptr(), hp[1].data_ptr(), cp[1].data_ptr(),
+            whh1t.data_ptr(), b1.data_ptr(), h[1].data_ptr(), c[1].data_ptr(), st))
+
+    out = {}
+    for name, fn, depth, by in (("lstm_step_lower_layer", lower, H, 4 * (4 * H + P)),
+                                ("lstm_step_upper_layer", upper, 2 * H, 4 * 5 * H)):
+        t = _timed(fn, iters)
+        flops = 3 * 2 * depth * 4 * H * rows          # three bf16 products per fp32 product
+        out[name] = {"us": t * 1e6, "flops_per_launch": flops, "TFLOPs_bf16": flops / t / 1e12,
+                     "GBps": by * rows / t / 1e9, "rows": rows}
+    return out
 
 
 # -- c5: the full model, conv encoder / decoder on 64x64 frames ----------------------------------
