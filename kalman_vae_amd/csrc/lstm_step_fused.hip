@@ -108,6 +108,14 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
                 for (int jj = 0; jj < 8; ++jj)
                     v[jj] = W[(long)(32 * (kk & 3) + 8 * s + jj) * SF_G4 + g * SF_H + unit0 + ub];
                 sf_split8(v, whi[ub][g][kk], wlo[ub][g][kk]);
+                // the matrix instruction reads its B operand from accumulation registers as
+                // well: keep the upper layer's weights there, so that the 256 ordinary
+                // registers hold the tiles in flight without copies between the two files
+                // (484 -> 406 instructions per tile).  Not for the lower layer: its P = 2
+                // instance then returns a wrong o gate for one row of a workgroup's first
+                // tile, intermittently (a compiler problem; the unpinned form is correct).
+                if constexpr (P == 0)
+                    asm volatile("" : "+a"(whi[ub][g][kk]), "+a"(wlo[ub][g][kk]));
             }
         }
     }
@@ -328,34 +336,15 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
     for (int r = 0; r < 4; ++r) cell_row(r, last);
 }
 
-}  // namespace kvae
+// The upper layer's instances are compiled apart (KVAE_SF_UPPER, with the compiler option that
+// keeps matrix-instruction results in ordinary registers: its accumulators are then read by
+// the cell update without copies, 406 -> 373 instructions per tile; the lower layer's
+// instances are slower with that option).
+int launch_lstm128_step_upper(long B, const float* x, const float* Wx, const float* h_prev,
+                              const float* c_prev, const float* WhhT, const float* bias,
+                              float* h_out, float* c_out, int cus, hipStream_t s);
 
-using namespace kvae;
-
-extern "C" {
-
-int kvae_lstm128_step_fused(long B, int P, const void* x, const void* Wx, const void* h_prev,
-                            const void* c_prev, const void* WhhT, const void* bias, void* h_out,
-                            void* c_out, void* stream) {
-    if (B < 1 || !x || !Wx || !WhhT || !bias || !h_out || !c_out ||
-        (h_prev == nullptr) != (c_prev == nullptr))
-        return KVAE_E_BADARG;
-    // wider inputs do not leave the registers for the tiles in flight: use kvae_lstm128_forward
-    if (P < 0 || P > 2) return KVAE_E_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(h_prev) | (P == 0 ? reinterpret_cast<uintptr_t>(x) : 0)) & 15)
-        return KVAE_E_BADARG;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess &&
-               hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-               n > 0) ? n : 256;
-    }
-    const long tiles = (B + 15) / 16;
-    hipStream_t s = (hipStream_t)stream;
-#define KVAE_SF_ARGS                                                                          \
-    B, (const float*)x, (const float*)Wx, (const float*)h_prev, (const float*)c_prev,         \
-        (const float*)WhhT, (const float*)bias, (float*)h_out, (float*)c_out
+#define KVAE_SF_ARGS B, x, Wx, h_prev, c_prev, WhhT, bias, h_out, c_out
 #define KVAE_SF_LAUNCH(P_, grid_)                                                             \
     do {                                                                                      \
         if (full && state)                                                                    \
@@ -368,25 +357,64 @@ int kvae_lstm128_step_fused(long B, int P, const void* x, const void* Wx, const 
             hipLaunchKernelGGL((lstm128_step_fused_kernel<P_, false, false>), grid_, dim3(256), \
                                0, s, KVAE_SF_ARGS);                                           \
     } while (0)
+
+#ifdef KVAE_SF_UPPER
+int launch_lstm128_step_upper(long B, const float* x, const float* Wx, const float* h_prev,
+                              const float* c_prev, const float* WhhT, const float* bias,
+                              float* h_out, float* c_out, int cus, hipStream_t s) {
     const bool full = B % 16 == 0, state = h_prev != nullptr;
-    if (P == 0) {
-        // tile walkers in groups of 8 (one per XCD), two workgroups (unit halves) per walker,
-        // one workgroup per compute unit
-        long groups = cus / 16;
-        if (groups < 1) groups = 1;
-        if ((tiles + 7) / 8 < groups) groups = (tiles + 7) / 8;
-        const dim3 grid((unsigned)(16 * groups));
-        KVAE_SF_LAUNCH(0, grid);
-    } else {
-        const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
-        if (P == 1)
-            KVAE_SF_LAUNCH(1, grid);
-        else
-            KVAE_SF_LAUNCH(2, grid);
+    const long tiles = (B + 15) / 16;
+    // tile walkers in groups of 8 (one per XCD), two workgroups (unit halves) per walker,
+    // one workgroup per compute unit
+    long groups = cus / 16;
+    if (groups < 1) groups = 1;
+    if ((tiles + 7) / 8 < groups) groups = (tiles + 7) / 8;
+    const dim3 grid((unsigned)(16 * groups));
+    KVAE_SF_LAUNCH(0, grid);
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+#endif
+
+}  // namespace kvae
+
+#ifndef KVAE_SF_UPPER
+using namespace kvae;
+
+extern "C" {
+
+int kvae_lstm128_step_fused(long B, int P, const void* x_, const void* Wx_, const void* h_prev_,
+                            const void* c_prev_, const void* WhhT_, const void* bias_,
+                            void* h_out_, void* c_out_, void* stream) {
+    if (B < 1 || !x_ || !Wx_ || !WhhT_ || !bias_ || !h_out_ || !c_out_ ||
+        (h_prev_ == nullptr) != (c_prev_ == nullptr))
+        return KVAE_E_BADARG;
+    // wider inputs do not leave the registers for the tiles in flight: use kvae_lstm128_forward
+    if (P < 0 || P > 2) return KVAE_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(h_prev_) | (P == 0 ? reinterpret_cast<uintptr_t>(x_) : 0)) & 15)
+        return KVAE_E_BADARG;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess &&
+               hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+               n > 0) ? n : 256;
     }
-#undef KVAE_SF_LAUNCH
-#undef KVAE_SF_ARGS
+    const float *x = (const float*)x_, *Wx = (const float*)Wx_, *h_prev = (const float*)h_prev_,
+                *c_prev = (const float*)c_prev_, *WhhT = (const float*)WhhT_,
+                *bias = (const float*)bias_;
+    float *h_out = (float*)h_out_, *c_out = (float*)c_out_;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0)
+        return launch_lstm128_step_upper(B, x, Wx, h_prev, c_prev, WhhT, bias, h_out, c_out, cus, s);
+    const bool full = B % 16 == 0, state = h_prev != nullptr;
+    const long tiles = (B + 15) / 16;
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    if (P == 1)
+        KVAE_SF_LAUNCH(1, grid);
+    else
+        KVAE_SF_LAUNCH(2, grid);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 
 }  // extern "C"
+#endif
