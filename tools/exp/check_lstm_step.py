@@ -1,3 +1,6 @@
+"""One-step LSTM layer kernel against a float64 torch layer: where (rows, units) the outputs differ,
+for the lower layer (P = 1, 2) and the upper layer (P = 0), and a sweep of the upper layer over
+sizes and seeds (three launches each).  Used when the register placement of the kernel changes."""
 import sys, torch
 sys.path.insert(0, ".")
 from kalman_vae_amd import _capi as capi
