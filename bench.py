@@ -615,7 +615,13 @@ def run_imputation(args, rank, world, dev, rehearsal):
                            "achieved": by / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": by / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": by, "avg_launch_us": sec * 1e6}
-        step = time_lstm_step_kernels(ssm, chunk) if args.net == "lstm" else None
+        step = None
+        if args.net == "lstm":
+            # operands as the workload has them: the state the network carries after a chunk
+            # (the clock the chip holds, and so the duration, depends on the values)
+            with torch.no_grad():
+                one_chunk()
+            step = time_lstm_step_kernels(ssm, chunk, a[-1], ssm.weight_model.hidden)
         if step is not None:
             # with the LSTM network the workload is T steps of its two layers per chunk, one
             # launch per layer and step; the upper layer's launch is the dominant kernel
@@ -636,12 +642,14 @@ def run_imputation(args, rank, world, dev, rehearsal):
     return res
 
 
-def time_lstm_step_kernels(ssm, rows, iters=10):
+def time_lstm_step_kernels(ssm, rows, x, hidden, iters=20):
     """HIP-event durations of the two launches that step the default LSTM network (two layers
-    of 128 units) once over ``rows`` sequences, as the masked filter issues them per time step;
-    None for any other network."""
+    of 128 units) once over ``rows`` sequences, as the masked filter issues them per time step,
+    from the carried state ``hidden`` = (h (2,rows,128), c (2,rows,128)) on the input x
+    (rows, a_dim); None for any other network."""
     lstm = getattr(ssm.weight_model, "lstm", None)
-    if lstm is None or lstm.num_layers != 2 or lstm.hidden_size != 128 or lstm.input_size > 2:
+    if (lstm is None or lstm.num_layers != 2 or lstm.hidden_size != 128 or lstm.input_size > 2
+            or hidden is None):
         return None
     from kalman_vae_amd import _capi as capi
     from kalman_vae_amd.lstm_function import _lstm2_operands
@@ -652,9 +660,7 @@ def time_lstm_step_kernels(ssm, rows, iters=10):
         w("weight_hh_l0"), w("bias_ih_l0"), w("bias_hh_l0"), w("weight_ih_l1"), w("weight_hh_l1"),
         w("bias_ih_l1"), w("bias_hh_l1"))
     wih0 = w("weight_ih_l0").contiguous()
-    g = torch.Generator(device="cpu").manual_seed(5)
-    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
-    x, hp, cp = rnd(rows, P), rnd(2, rows, H), rnd(2, rows, H)
+    x, hp, cp = x.contiguous(), hidden[0].contiguous(), hidden[1].contiguous()
     h, c = torch.empty(2, rows, H, device=dev), torch.empty(2, rows, H, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
