@@ -54,8 +54,9 @@ for i in range(cases):
                                 mask_kind=rng.choice(["none", "binary", "fractional"]),
                                 sample=rng.random() < 0.5, symmetrize=sym)
         elif kind == "loss":
-            KC.check_loss(be, T=max(T, 2), B=B, n=n, p=p, K=K, dtype=dtype, seed=5000 + i,
-                          mask_kind=rng.choice(["none", "binary"]), symmetrize=sym, burn_in=burn)
+            loss_args = dict(T=max(T, 2), B=B, n=n, p=p, K=K, dtype=dtype, seed=5000 + i,
+                             mask_kind=rng.choice(["none", "binary"]), symmetrize=sym, burn_in=burn)
+            KC.check_loss(be, **loss_args)
         elif kind == "masked_grad":
             no, po, Ko = rng.choice(SMALL + ODD)
             TMG.run_case(no, po, Ko, dtype, sample=rng.random() < 0.5, burn_in=burn,
@@ -100,6 +101,8 @@ for i in range(cases):
                 args = dict(T=T, B=B, n=n, p=p, K=K, dtype=dtype)
                 if kind == "elbo":
                     KC.check_elbo(host, seed=3000 + i, **args)
+                elif kind == "loss":
+                    KC.check_loss(host, **loss_args)
             except Exception:  # noqa: BLE001
                 alike = True
         (conditioning if alike else failures).append(msg)
