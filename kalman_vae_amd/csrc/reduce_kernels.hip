@@ -49,13 +49,16 @@ struct ColumnSumParts {
     long rows[COLSUM_MAX_PARTS];
     int cols[COLSUM_MAX_PARTS];
     int first_block[COLSUM_MAX_PARTS + 1];
+    int wide[COLSUM_MAX_PARTS];     // 1: a lane sums four adjacent columns (16-byte loads)
     const T* in[COLSUM_MAX_PARTS];
     T* out[COLSUM_MAX_PARTS];
 };
+// Every column is summed in the same order in both forms (rows wave, wave + W, ... in four
+// interleaved partial sums, then the wavefronts in order), so they give identical results.
 template <typename T>
 __global__ void __launch_bounds__(64 * COLSUM_WAVES)
 column_sum_many_kernel(int parts, ColumnSumParts<T> p) {
-    __shared__ T sm[COLSUM_WAVES][64];
+    __shared__ T sm[COLSUM_WAVES][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int k = 0;
 #pragma unroll
@@ -64,6 +67,44 @@ column_sum_many_kernel(int parts, ColumnSumParts<T> p) {
     const long rows = p.rows[k];
     const int cols = p.cols[k];
     const T* __restrict__ in = p.in[k];
+    if (p.wide[k]) {                 // the same for the whole workgroup
+        if constexpr (sizeof(T) == 4) {
+            const int c = ((int)blockIdx.x - p.first_block[k]) * 256 + 4 * lane;
+            float4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < cols) {
+                for (long r = wave; r < rows; r += 4 * COLSUM_WAVES) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long rr = r + (long)u * COLSUM_WAVES;
+                        if (rr < rows) {
+                            const float4 v = *reinterpret_cast<const float4*>(in + rr * cols + c);
+                            acc[u].x += v.x;
+                            acc[u].y += v.y;
+                            acc[u].z += v.z;
+                            acc[u].w += v.w;
+                        }
+                    }
+                }
+            }
+            sm[wave][4 * lane + 0] = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+            sm[wave][4 * lane + 1] = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+            sm[wave][4 * lane + 2] = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+            sm[wave][4 * lane + 3] = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+            __syncthreads();
+            // 256 columns, one per lane of the first four wavefronts
+            const int cc = threadIdx.x;
+            const int col = ((int)blockIdx.x - p.first_block[k]) * 256 + cc;
+            if (cc < 256 && col < cols) {
+                T s = T(0);
+#pragma unroll
+                for (int w = 0; w < COLSUM_WAVES; ++w) s += sm[w][cc];
+                p.out[k][col] = s;
+            }
+        }
+        return;
+    }
     const int c = ((int)blockIdx.x - p.first_block[k]) * 64 + lane;
     T acc[4] = {T(0), T(0), T(0), T(0)};
     if (c < cols) {
@@ -97,7 +138,10 @@ int launch_column_sum_many(int parts, const long* rows, const int* cols, const v
         p.first_block[i] = blocks;
         p.in[i] = (const T*)in[i];
         p.out[i] = (T*)out[i];
-        blocks += (cols[i] + 63) / 64;
+        // many columns, rows that start on 16-byte boundaries: four columns per lane
+        p.wide[i] = sizeof(T) == 4 && cols[i] >= 1024 && cols[i] % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(in[i]) & 15) == 0;
+        blocks += p.wide[i] ? (cols[i] + 255) / 256 : (cols[i] + 63) / 64;
     }
     p.first_block[parts] = blocks;
     hipLaunchKernelGGL((column_sum_many_kernel<T>), dim3(blocks), dim3(64 * COLSUM_WAVES), 0, s,
