@@ -253,6 +253,11 @@ int kvae_column_sum(long rows, int cols, int dtype, const void* in, void* out, v
     if (rows < 0 || cols < 1 || !in || !out) return KVAE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((cols + 63) / 64), block(64 * kvae::COLSUM_WAVES);
+    // many float columns: the four-columns-per-lane form of the multi-matrix kernel (the
+    // same summation order, hence the same bits)
+    if (dtype == KVAE_F32 && cols >= 1024 && cols % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(in) & 15) == 0)
+        return kvae::launch_column_sum_many<float>(1, &rows, &cols, &in, &out, s);
     if (dtype == KVAE_F32)
         hipLaunchKernelGGL((kvae::column_sum_kernel<float>), grid, block, 0, s, rows, cols,
                            (const float*)in, (float*)out);

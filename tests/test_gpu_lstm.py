@@ -301,6 +301,18 @@ def test_column_sum_many_equals_separate_sums():
         got = capi.column_sum_many(xs)
         for x, g in zip(xs, got):
             assert torch.equal(g, capi.column_sum(x))
+    # wide float matrices take a four-columns-per-lane form (16-byte loads); a copy at an
+    # address that is not a multiple of 16 takes the one-column-per-lane form: same bits,
+    # and both equal a float64 sum to rounding
+    for rows, cols in ((64, 196608), (256, 1024), (37, 70000)):
+        x = torch.randn(rows, cols, device=dev)
+        shifted = torch.empty(rows * cols + 1, device=dev)[1:].view(rows, cols)
+        shifted.copy_(x)
+        assert shifted.data_ptr() % 16 != 0
+        wide, narrow = capi.column_sum(x), capi.column_sum(shifted)
+        assert torch.equal(wide, narrow)
+        want = x.double().sum(0)
+        assert float((wide.double() - want).abs().max()) < 1e-5 * float(x.double().abs().sum(0).max())
     assert len(capi.column_sum_many(xs[:1])) == 1
     with pytest.raises(RuntimeError):
         capi.column_sum_many(xs + xs[:1])
