@@ -252,3 +252,22 @@ def test_evaluation_masks_and_pixel_metric():
     mask = torch.tensor([[1.], [0.]])
     assert float(calculate_fraction_of_incorrect_pixels(image, recon, mask)) == 0.25
     assert torch.isnan(calculate_fraction_of_incorrect_pixels(image, recon, torch.ones(2, 1)))
+
+
+def test_stepping_network_applies_only_on_the_gpu():
+    """The per-step form of the LSTM network (three launches a step, used by the masked
+    filter without a gradient) exists only for float32 tensors on a GPU: on the CPU the
+    module offers no stepper, so the masked filter keeps calling it once per step, and a
+    step-by-step call still equals the whole-sequence call (the carried state)."""
+    from kalman_vae_amd.dynamics_parameter_network import LSTMModel
+    torch.manual_seed(0)
+    net = LSTMModel(2, 3, hidden_dim=128, num_layers=2).eval()
+    x = torch.randn(5, 4, 2)
+    with torch.no_grad():
+        assert net.inference_stepper(x[0]) is None
+        net.clear_hidden_state()
+        whole = net(x)
+        net.clear_hidden_state()
+        steps = torch.cat([net(x[t:t + 1]) for t in range(5)])
+    assert torch.allclose(whole, steps, atol=1e-6)
+    assert abs(float(whole.sum()) - 5 * 4) < 1e-4        # rows of softmax weights
