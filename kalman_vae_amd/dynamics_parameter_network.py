@@ -76,8 +76,17 @@ class LSTMModel(nn.Module):
             return lstm_function.softmax_head(h, self.linear, lead)
         if self.hidden is None:
             self.reset_hidden_state(x.size(1), device=x.device, dtype=x.dtype)
-        h, self.hidden = self.lstm(x, self.hidden)
+        h, self.hidden = self._library_lstm(x)
         return lstm_function.softmax_head(h, self.linear, lead)
+
+    def _library_lstm(self, x):
+        """self.lstm(x, self.hidden) through torch.  MIOpen refuses the backward of an LSTM
+        that ran in eval mode, so a run in eval mode that records a gradient (masked
+        sequences of an evaluation that differentiates) takes PyTorch's native kernels."""
+        if x.is_cuda and not self.training and torch.is_grad_enabled():
+            with torch.backends.cudnn.flags(enabled=False):
+                return self.lstm(x, self.hidden)
+        return self.lstm(x, self.hidden)
 
     def inference_stepper(self, x):
         """For a caller that feeds one step at a time without a gradient (the masked

@@ -62,11 +62,11 @@ def replay_draws(g, dtype, device):
 
 
 def run_module(g, dtype, monkeypatch, fused=False):
-    # MIOpen refuses the backward of an fp32 LSTM that ran in eval mode (the
-    # reference on a GPU hits the same limit); these fixtures differentiate
-    # eval-mode runs, so use PyTorch's native LSTM kernels for them.
-    with torch.backends.cudnn.flags(enabled=False):
-        return _run_module(g, dtype, monkeypatch, fused)
+    # MIOpen refuses the backward of an fp32 LSTM that ran in eval mode (the reference on a
+    # GPU hits the same limit); these fixtures differentiate eval-mode runs.  The module
+    # itself switches to PyTorch's native LSTM kernels for such a call
+    # (LSTMModel._library_lstm), so nothing is set here.
+    return _run_module(g, dtype, monkeypatch, fused)
 
 
 def _run_module(g, dtype, monkeypatch, fused=False):
