@@ -391,6 +391,39 @@ def test_masked_inference_with_stepping_network_equals_per_step_tensors(mode, B,
     assert Fn.read_status(dev) == 0
 
 
+def test_filter_step_into_checks_its_operands():
+    """functions.filter_step_into writes into the caller's tensors: it must refuse operands
+    whose shapes or layout would make the kernel write elsewhere, and equal the allocating
+    one-step call otherwise."""
+    import kalman_vae_amd.functions as Fn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, n, p, K = 33, 4, 2, 3
+    r = lambda *s: torch.randn(*s, device=dev)
+    spd = lambda k: (lambda m: m @ m.T + k * torch.eye(k, device=dev))(r(k, k))
+    a, alpha, mask = r(1, B, p), torch.softmax(r(2, B, K), -1), torch.ones(1, B, device=dev)
+    A_K, C_K, Q, R = 0.3 * r(K, n, n), r(K, p, n), spd(n), spd(p)
+    m_in, P_in = r(B, n), torch.stack([spd(n) for _ in range(B)])
+    new = lambda *s: torch.full(s, float("nan"), device=dev)
+    outs = [new(1, B, n), new(1, B, n, n), new(1, B, n), new(1, B, n, n), new(2, B, n, n),
+            new(2, B, p, n)]
+    Fn.filter_step_into(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, *outs)
+    want = Fn.kalman_filter_steps(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, want_mats=True)
+    for x, y in zip(outs, want):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError, match="contiguous"):
+        Fn.filter_step_into(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in,
+                            new(1, B, 2 * n)[..., ::2], *outs[1:])
+    with pytest.raises(ValueError, match="shapes"):
+        Fn.filter_step_into(a, alpha, mask, A_K, C_K, Q, R, m_in, P_in, *outs[:4],
+                            new(1, B, n, n), outs[5])
+    with pytest.raises(ValueError, match="shapes"):
+        Fn.filter_step_into(a, alpha[:1], mask, A_K, C_K, Q, R, m_in, P_in, *outs)
+    with pytest.raises(ValueError, match="out must be"):
+        Fn.impute_observation(alpha[0], A_K, C_K, m_in, a[0], mask[0], out=new(B, p + 1))
+    assert Fn.read_status(dev) == 0
+
+
 def test_module_large_state_backward_runs_the_register_tile_kernel():
     """The module's training path at a large state dimension (fp32, z_dim=32): the filter
     backward must run the register-tile kernel (it needs the mixed per-step matrices the
