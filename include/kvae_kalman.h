@@ -242,7 +242,13 @@ int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
  *   total); outputs d_a (T,B,p), d_alpha (T+1,B,K) and the parameter gradients summed
  *   over T and B (overwritten).  d->burn_in as in the separate calls.
  * Small state dimensions (those kvae_loss_supported() reports).  Deterministic: no
- * float atomics.                                                                  */
+ * float atomics.
+ * Three kernel forms serve these calls, chosen from the dimensions (KVAE_SEQ_LANES=1|4|16
+ * in the environment forces one): one lane per sequence (large batches), four lanes per
+ * sequence, and 16 lanes per sequence with the per-step state in LDS (float, n and p up to
+ * 4, T <= 36, up to 8192 sequences).  In the last form the forward call writes nothing to
+ * `saved` (kvae_loss_saved_bytes() is then 256) and the backward call recomputes the
+ * forward pass on chip instead of reading it back.                                 */
 typedef struct {
     const void *a;        /* (T,B,p)                                             */
     const void *alpha;    /* (T+1,B,K)                                           */
@@ -271,6 +277,21 @@ int kvae_kalman_loss_forward(const kvae_dims *d, const kvae_loss_fwd *io, void *
                              size_t workspace_bytes, void *stream);
 int kvae_kalman_loss_backward(const kvae_dims *d, const kvae_loss_bwd *io, void *workspace,
                               size_t workspace_bytes, void *stream);
+
+/* Both directions in one call, for the training step, which always differentiates the
+ * objective it has just evaluated (examples/train.py:115-131 of the reference: elbo(...)
+ * followed by (-elbo).backward()): everything kvae_kalman_loss_forward writes (io->fwd.out,
+ * io->fwd.terms) and everything kvae_kalman_loss_backward writes, for the cotangents in
+ * io->g_scale (NULL = 1 for each of the three totals, i.e. the gradient of out[3]; a caller
+ * that learns the real cotangent later multiplies by it: the gradient is linear in it).
+ * While a sequence's per-step state fits on chip (float, n and p up to 4, T <= 36, a modest
+ * batch: 16 lanes per sequence, state in LDS) this is ONE launch that reads a, alpha, eps and
+ * writes d_a, d_alpha and per-wavefront sums: no mean or covariance goes through device
+ * memory and io->fwd.saved is not touched.  Otherwise it is the two calls above in a row
+ * (io->fwd.saved and io->g_scale are then required).
+ * Workspace: kvae_workspace_bytes(d, KVAE_OP_LOSS_VALUE_AND_GRAD).                  */
+int kvae_kalman_loss_value_and_grad(const kvae_dims *d, const kvae_loss_bwd *io, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* One step of the masked filter's imputation, kvae/state_space_model.py:232-277, for
  * every sequence: z = A(w) m_pred (+ L_Q eps_z), a_imp = C(w) z (+ L_R eps_a),
@@ -628,7 +649,7 @@ int kvae_graph_count_kernel_nodes(void *hip_graph);
 /* ------------------------------------------------------------------------ */
 enum {
     KVAE_OP_FILTER_BWD = 1, KVAE_OP_SMOOTH_BWD = 2, KVAE_OP_ELBO_BWD = 3,
-    KVAE_OP_LOSS_FWD = 4, KVAE_OP_LOSS_BWD = 5
+    KVAE_OP_LOSS_FWD = 4, KVAE_OP_LOSS_BWD = 5, KVAE_OP_LOSS_VALUE_AND_GRAD = 6
 };
 
 /* Scratch bytes an entry point with a workspace argument needs (per-wave partial

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("KVAE_LIB_PATH") or os.path.join(_HERE, "csrc", "libkv
 
 KVAE_F32, KVAE_F64 = 0, 1
 OP_FILTER_BWD, OP_SMOOTH_BWD, OP_ELBO_BWD, OP_LOSS_FWD, OP_LOSS_BWD = 1, 2, 3, 4, 5
+OP_LOSS_VALUE_AND_GRAD = 6
 
 STATUS_BITS = {
     1: "innovation covariance C P C^T + R is not positive definite",
@@ -85,7 +86,8 @@ EXPORTS = (
     "kvae_filter_backward_noalloc", "kvae_noalloc_scratch_bytes",
     "kvae_smooth_forward", "kvae_smooth_backward", "kvae_filter_smooth_forward",
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
-    "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_loss_saved_bytes",
+    "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_kalman_loss_value_and_grad",
+    "kvae_loss_saved_bytes",
     "kvae_loss_supported",
     "kvae_filter_forward_masked_mlp", "kvae_predict_future",
     "kvae_filter_smooth_fused", "kvae_filter_smooth_fused_workspace_bytes",
@@ -152,6 +154,9 @@ def declare(lib, prefix="kvae_", with_stream=True):
                                        + (ws + tail if with_stream else []))
         spec["kalman_loss_backward"] = ([C.POINTER(Dims), C.POINTER(LossBwd)]
                                         + (ws + tail if with_stream else []))
+    if hasattr(lib, prefix + "kalman_loss_value_and_grad"):
+        spec["kalman_loss_value_and_grad"] = ([C.POINTER(Dims), C.POINTER(LossBwd)]
+                                              + (ws + tail if with_stream else []))
     for name, argtypes in spec.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes = argtypes

@@ -418,6 +418,7 @@ size_t kvae_workspace_bytes(const kvae_dims* d, int op) {
             return (size_t)pair_rows((long)d->T * d->B) * (n * n + p * p + n + n * n) * el;
         case KVAE_OP_LOSS_FWD:
         case KVAE_OP_LOSS_BWD:
+        case KVAE_OP_LOSS_VALUE_AND_GRAD:
             return loss_workspace_bytes(d, op);
         default:
             return 0;

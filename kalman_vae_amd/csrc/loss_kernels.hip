@@ -107,20 +107,32 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const R* partial, long
     }
 }
 
-// Four lanes per sequence while one lane per sequence would leave SIMDs without a
-// wavefront (the chip has 1024); KVAE_SEQ_LANES=1|4 forces one form (tests, timing).
-inline bool loss_use_quad(int n, int p, long B) {
-    if (n > 4 || p > 4) return false;
+// Which form runs a call: 16 lanes per sequence (row form, loss_row_kernels.hip) while that
+// gives at most two wavefronts per SIMD, four lanes per sequence (quad form) while one lane
+// per sequence would leave SIMDs without a wavefront (the chip has 1024), else one lane per
+// sequence.  KVAE_SEQ_LANES=1|4|16 forces a form where it exists (tests, timing).  The row
+// form needs its per-step state to fit LDS (T <= 36) and exists for float only; its forward
+// call writes nothing into `saved` and its backward call reads nothing from it, so both
+// calls of a pair must take the same decision: it depends on the dimensions and the
+// environment only.
+constexpr long LOSS_ROW_MAX_B = 8192;
+inline int loss_form(const kvae_dims* d) {
     const char* e = getenv("KVAE_SEQ_LANES");
     const int forced = e ? atoi(e) : 0;
-    if (forced == 1) return false;
-    if (forced == 4) return true;
-    return B < 32768;
+    const bool quad_ok = d->n <= 4 && d->p <= 4;
+    const bool row_ok = row_loss_supported(d->n, d->p, d->K, d->dtype, d->T, 1) != 0;
+    if (forced == 16 && row_ok) return 16;
+    if (forced == 4 && quad_ok) return 4;
+    if (forced == 1) return 1;
+    if (forced == 0 && row_ok && d->B <= LOSS_ROW_MAX_B) return 16;
+    if (quad_ok && d->B < 32768) return 4;
+    return 1;
 }
-// wavefronts (= rows of partial sums) of a launch
-inline long loss_rows(int n, int p, long B) {
-    const long per_wave = loss_use_quad(n, p, B) ? LOSS_QUAD_SEQS : LOSS_BLOCK;
-    return (B + per_wave - 1) / per_wave;
+inline bool loss_use_quad(const kvae_dims* d) { return loss_form(d) == 4; }
+// wavefronts (= rows of partial sums) of a launch of the lane / quad forms
+inline long loss_rows(const kvae_dims* d) {
+    const long per_wave = loss_use_quad(d) ? LOSS_QUAD_SEQS : LOSS_BLOCK;
+    return (d->B + per_wave - 1) / per_wave;
 }
 // the larger of the two forms, for workspace sizing that does not depend on the environment
 inline long loss_rows_max(int n, int p, long B) {
@@ -154,12 +166,13 @@ LossFwdArgs<R> make_loss_args(const kvae_dims* d, const kvae_loss_fwd* io, void*
 template <typename R, int N, int P, int K>
 int run_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io, void* ws, size_t ws_bytes,
                      hipStream_t s) {
-    const long rows = loss_rows(N, P, d->B);
+    if (loss_form(d) == 16) return row_loss_forward(d, io, ws, ws_bytes, s);
+    const long rows = loss_rows(d);
     if (ws_bytes < (size_t)rows * 3 * sizeof(R)) return KVAE_E_WORKSPACE;
     LossFwdArgs<R> g = make_loss_args<R>(d, io, ws);
     bool launched = false;
     if constexpr (N <= 4 && P <= 4) {
-        if (loss_use_quad(N, P, d->B)) {
+        if (loss_use_quad(d)) {
             hipLaunchKernelGGL((loss_forward_quad_kernel<R, N, P, K>), dim3(rows),
                                dim3(LOSS_BLOCK), 0, s, g);
             launched = true;
@@ -177,7 +190,8 @@ template <typename R, int N, int P, int K>
 int run_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io, void* ws, size_t ws_bytes,
                       hipStream_t s) {
     using PG = LossParamGrads<N, P, K>;
-    const long rows = loss_rows(N, P, d->B);
+    if (loss_form(d) == 16) return row_loss_backward(d, io, ws, ws_bytes, s, 0);
+    const long rows = loss_rows(d);
     const size_t bars = (size_t)loss_bars_elems(d->T, d->B, d->n) * sizeof(R);
     if (ws_bytes < bars + (size_t)rows * PG::LEN * sizeof(R)) return KVAE_E_WORKSPACE;
     LossBwdArgs<R> g;
@@ -194,7 +208,7 @@ int run_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io, void* ws, siz
     g.partial = (R*)((char*)ws + bars);
     bool launched = false;
     if constexpr (N <= 4 && P <= 4) {
-        if (loss_use_quad(N, P, d->B)) {
+        if (loss_use_quad(d)) {
             hipLaunchKernelGGL((loss_backward_quad_kernel<R, N, P, K>), dim3(rows),
                                dim3(LOSS_BLOCK), 0, s, g);
             launched = true;
@@ -227,10 +241,14 @@ size_t loss_workspace_bytes(const kvae_dims* d, int op) {
     const size_t el = d->dtype == KVAE_F32 ? 4 : 8;
     const long n = d->n, p = d->p, K = d->K;
     const long rows = loss_rows_max(d->n, d->p, d->B);
-    if (op == KVAE_OP_LOSS_FWD) return (size_t)rows * 3 * el;
-    if (op == KVAE_OP_LOSS_BWD)
-        return ((size_t)loss_bars_elems(d->T, d->B, n) +
-                (size_t)rows * (K * n * n + K * p * n + n * n + p * p + n + n * n)) * el;
+    // the row form (float, n and p up to 4) keeps one row of sums per four sequences
+    const size_t row_form = (d->n <= 4 && d->p <= 4) ? row_loss_workspace_bytes(d) : 0;
+    const size_t fwd = (size_t)rows * 3 * el;
+    const size_t bwd = ((size_t)loss_bars_elems(d->T, d->B, n) +
+                        (size_t)rows * (K * n * n + K * p * n + n * n + p * p + n + n * n)) * el;
+    if (op == KVAE_OP_LOSS_FWD) return fwd > row_form ? fwd : row_form;
+    if (op == KVAE_OP_LOSS_BWD || op == KVAE_OP_LOSS_VALUE_AND_GRAD)
+        return bwd > row_form ? bwd : row_form;
     return 0;
 }
 
@@ -253,6 +271,7 @@ int kvae_loss_supported(int n, int p, int K, int dtype) {
 
 size_t kvae_loss_saved_bytes(const kvae_dims* d) {
     if (!dims_ok(d)) return 0;
+    if (loss_form(d) == 16) return 256;   // the row form saves nothing: its backward recomputes
     return (size_t)loss_saved_elems(d->T, d->B, d->n) * (d->dtype == KVAE_F32 ? 4 : 8);
 }
 
@@ -279,6 +298,22 @@ int kvae_kalman_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io, void*
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
     return KVAE_E_UNSUPPORTED;
+}
+
+int kvae_kalman_loss_value_and_grad(const kvae_dims* d, const kvae_loss_bwd* io, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!dims_ok(d) || !io || !io->fwd.a || !io->fwd.alpha || !io->fwd.A_K || !io->fwd.C_K ||
+        !io->fwd.Q || !io->fwd.R || !io->fwd.m0 || !io->fwd.P0 || !io->fwd.eps || !io->fwd.out ||
+        !io->d_a || !io->d_alpha || !workspace)
+        return KVAE_E_BADARG;
+    if (!loss_dims_supported(d->n, d->p, d->K)) return KVAE_E_UNSUPPORTED;
+    if (loss_form(d) == 16)
+        return row_loss_backward(d, io, workspace, workspace_bytes, (hipStream_t)stream, 1);
+    // the other forms hand their state over through `saved`: two launches
+    if (!io->fwd.saved || !io->g_scale) return KVAE_E_BADARG;
+    const int rc = kvae_kalman_loss_forward(d, &io->fwd, workspace, workspace_bytes, stream);
+    if (rc != KVAE_OK) return rc;
+    return kvae_kalman_loss_backward(d, io, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -27,6 +27,17 @@ int wave_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, si
 // (op = KVAE_OP_LOSS_FWD / KVAE_OP_LOSS_BWD), 0 when (n, p, K) has no such kernel.
 size_t loss_workspace_bytes(const kvae_dims* d, int op);
 
+// Row form of the fused objective (loss_row_kernels.hip: one sequence over 16 lanes, per-step
+// state in LDS, fp32, n and p up to 4).  row_loss_backward recomputes the forward pass and so
+// needs nothing saved; with_value it also writes the forward call's outputs.
+long row_loss_rows(long B);
+int row_loss_supported(int n, int p, int K, int dtype, int T, int grad);
+size_t row_loss_workspace_bytes(const kvae_dims* d);
+int row_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io, void* ws, size_t ws_bytes,
+                     hipStream_t s);
+int row_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io, void* ws, size_t ws_bytes,
+                      hipStream_t s, int with_value);
+
 // Register-tile kernels (tile_kernels.hip): fp32, n and p multiples of 8 up to 32.
 // KVAE_E_UNSUPPORTED means "use the LDS kernels".
 int tile_supported(int n, int p, int dtype);

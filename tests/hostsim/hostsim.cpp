@@ -17,6 +17,7 @@
 #include "../../kalman_vae_amd/csrc/kalman_rollout.h"
 #include "../../kalman_vae_amd/csrc/kalman_filter_smooth.h"
 #include "../../kalman_vae_amd/csrc/kalman_wave.h"
+#include "../../kalman_vae_amd/csrc/kalman_row.h"
 #include <memory>
 
 using namespace kvae;
@@ -373,6 +374,132 @@ int welbo_bwd(const kvae_dims* d, const kvae_elbo_bwd* io) {
 }
 }  // namespace
 
+
+// ---- row form (kalman_row.h): the 16 lanes of a sequence as an array ---------------------
+namespace {
+template <typename R, bool GRAD>
+struct HostRowEnv {
+    using V = row::Row<R>;
+    using SL = row::Slots<GRAD>;
+    std::vector<R> lds;
+    explicit HostRowEnv(int T) : lds((size_t)T * SL::STEP, R(0)) {}
+    V scalar(const R* p) const { return V(*p); }
+    void fence() const {}
+    template <int LEN>
+    V vec_c(const R* p) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = (l & 3) < LEN ? p[l & 3] : R(0);
+        return x;
+    }
+    template <int LEN>
+    V vec_r(const R* p) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = (l >> 2) < LEN ? p[l >> 2] : R(0);
+        return x;
+    }
+    template <int ROWS, int COLS, int LAY, bool PAD>
+    V mat(const R* p) const {
+        V x;
+        for (int l = 0; l < 16; ++l) {
+            const int r = row::lay_r(LAY, l >> 2, l & 3), c = row::lay_c(LAY, l >> 2, l & 3);
+            x.v[l] = (r < ROWS && c < COLS) ? p[r * COLS + c] : (PAD && r == c ? R(1) : R(0));
+        }
+        return x;
+    }
+    void put_scalar(R* p, const V& x) const { *p = x.v[0]; }
+    template <int LEN>
+    void put_vec_c(R* p, const V& xc) const {
+        for (int j = 0; j < LEN; ++j) p[j] = xc.v[j];
+    }
+    void st_mat(int t, int slot, const V& x) {
+        for (int l = 0; l < 16; ++l) lds[(size_t)t * SL::STEP + slot + l] = x.v[l];
+    }
+    template <int LAY>
+    V ld_mat(int t, int slot) const {
+        V x;
+        for (int l = 0; l < 16; ++l)
+            x.v[l] = lds[(size_t)t * SL::STEP + slot + 4 * row::lay_r(LAY, l >> 2, l & 3) +
+                         row::lay_c(LAY, l >> 2, l & 3)];
+        return x;
+    }
+    void st_vec(int t, int slot, const V& xc) {
+        for (int j = 0; j < 4; ++j) lds[(size_t)t * SL::STEP + slot + j] = xc.v[j];
+    }
+    V ld_vec_c(int t, int slot) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = lds[(size_t)t * SL::STEP + slot + (l & 3)];
+        return x;
+    }
+    V ld_vec_r(int t, int slot) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = lds[(size_t)t * SL::STEP + slot + (l >> 2)];
+        return x;
+    }
+};
+
+template <typename R, int N, int P, int K, bool GRAD>
+int row_loss(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* bio) {
+    using V = row::Row<R>;
+    LossBwdArgs<R> g;
+    g.f = mkl<R>(d, fio);
+    g.burn_in = d->burn_in;
+    g.g_scale = bio ? (const R*)bio->g_scale : nullptr;
+    g.g_scale_stride = bio ? bio->g_scale_stride : 0;
+    g.w_obs = (R)fio->w_obs; g.w_trans = (R)fio->w_trans; g.w_post = (R)fio->w_post;
+    g.d_a = bio ? (R*)bio->d_a : nullptr; g.d_alpha = bio ? (R*)bio->d_alpha : nullptr;
+    g.partial = nullptr;
+    V sums[3] = {V(R(0)), V(R(0)), V(R(0))};
+    row::RowAcc<V, K> acc;
+    row::zero_acc(acc);
+    int st = 0;
+    for (int b = 0; b < d->B; ++b) {
+        HostRowEnv<R, GRAD> env(d->T);
+        row::loss_row_sequence<V, R, N, P, K, GRAD>(env, g, (long)b, sums, acc, st);
+    }
+    if (st && fio->status) *fio->status |= st;
+    if (fio->out) {
+        R* out = (R*)fio->out;
+        out[0] = (R)fio->w_obs * sums[0].v[0];
+        out[1] = (R)fio->w_trans * sums[1].v[0];
+        out[2] = (R)fio->w_post * sums[2].v[0];
+        out[3] = out[0] + out[1] + out[2];
+    }
+    if (GRAD) {
+        auto mat_out = [&](void* dst, const V& nat, const V* trn, int rows, int cols) {
+            if (!dst) return;
+            R* o = (R*)dst;
+            for (int i = 0; i < rows; ++i)
+                for (int j = 0; j < cols; ++j)
+                    o[i * cols + j] = nat.v[4 * i + j] + (trn ? trn->v[4 * j + i] : R(0));
+        };
+        for (int k = 0; k < K; ++k) {
+            mat_out(bio->d_A_K ? (R*)bio->d_A_K + k * N * N : nullptr, acc.AK[k], &acc.AKT[k], N, N);
+            mat_out(bio->d_C_K ? (R*)bio->d_C_K + k * P * N : nullptr, acc.CK[k], nullptr, P, N);
+        }
+        mat_out(bio->d_Q, acc.Q, nullptr, N, N);
+        mat_out(bio->d_R, acc.Rm, nullptr, P, P);
+        mat_out(bio->d_P0, acc.P0, nullptr, N, N);
+        if (bio->d_m0)
+            for (int j = 0; j < N; ++j) ((R*)bio->d_m0)[j] = acc.m0c.v[j];
+    }
+    return 0;
+}
+template <typename R, int N, int P, int K>
+int row_loss_fwd(const kvae_dims* d, const kvae_loss_fwd* io) {
+    return row_loss<R, N, P, K, false>(d, io, nullptr);
+}
+template <typename R, int N, int P, int K>
+int row_loss_bwd(const kvae_dims* d, const kvae_loss_bwd* io) {
+    kvae_loss_fwd f = io->fwd;
+    f.out = nullptr;
+    f.terms = nullptr;
+    f.status = nullptr;
+    return row_loss<R, N, P, K, true>(d, &f, io);
+}
+}  // namespace
+
+#define ROW_DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(4, 2, 8)
+
 #define WAVE_DIM_LIST(X) X(32, 16, 8) X(16, 8, 4) X(6, 3, 2) X(4, 2, 3)
 
 #define DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(8, 4, 4) X(4, 2, 8)
@@ -468,6 +595,19 @@ int hostsim_kalman_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io) {
 int hostsim_kalman_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io) {
 #define FN loss_bwd
     DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+
+int hostsim_row_kalman_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io) {
+#define FN row_loss_fwd
+    ROW_DIM_LIST(CASE)
+    return KVAE_E_UNSUPPORTED;
+#undef FN
+}
+int hostsim_row_kalman_loss_backward(const kvae_dims* d, const kvae_loss_bwd* io) {
+#define FN row_loss_bwd
+    ROW_DIM_LIST(CASE)
     return KVAE_E_UNSUPPORTED;
 #undef FN
 }

@@ -239,6 +239,22 @@ def check_loss(backend, T, B, n, p, K, dtype, seed=0, mask_kind="none", symmetri
     bwd = backend.loss_backward(fwd, g_scale, stride, symmetrize=symmetrize, burn_in=burn_in)
     for k in wrt:
         _cmp("d_" + k, bwd["d_" + k], gref[k], tol, failures)
+    if backend.kind == "hip":
+        # the same results from the one-call form
+        both = backend.loss_value_and_grad(dv["a"], dv["alpha"], dv["mask"], dv["A_K"], dv["C_K"],
+                                           dv["Q"], dv["R"], dv["m0"], dv["P0"], dv["eps_e"],
+                                           weights, g_scale, stride, symmetrize=symmetrize,
+                                           burn_in=burn_in)
+        assert int(both["status"].item()) == 0
+        for i, k in enumerate(("obs", "trans", "post")):
+            _cmp("both.terms." + k, both["terms"][i], e[k], tol, failures)
+        got = both["out"].double().cpu()
+        if not (float((got[:3] - totals.detach()).abs().max()) < tol * float(scale.detach())):
+            failures.append(f"both.out[0:3]: {got[:3].tolist()} vs {totals.tolist()}")
+        if not (abs(float(got[3] - totals.detach().sum())) < tol * float(scale.detach())):
+            failures.append(f"both.out[3]: {float(got[3])} vs {float(totals.detach().sum())}")
+        for k in wrt:
+            _cmp("both.d_" + k, both["d_" + k], gref[k], tol, failures)
     assert not failures, "\n".join(failures)
 
 

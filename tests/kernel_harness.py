@@ -25,7 +25,7 @@ def hostsim_lib():
         src = os.path.join(HOSTSIM_DIR, "hostsim.cpp")
         csrc = os.path.join(HERE, "..", "kalman_vae_amd", "csrc")
         deps = [src, os.path.join(csrc, "kalman_core.h"), os.path.join(csrc, "kalman_wave.h"),
-                os.path.join(csrc, "kalman_loss.h")]
+                os.path.join(csrc, "kalman_loss.h"), os.path.join(csrc, "kalman_row.h")]
         stale = (not os.path.exists(HOSTSIM_LIB)
                  or os.path.getmtime(HOSTSIM_LIB) < max(os.path.getmtime(f) for f in deps))
         if stale:
@@ -34,6 +34,10 @@ def hostsim_lib():
         _hostsim = C.CDLL(HOSTSIM_LIB)
         capi.declare(_hostsim, prefix="hostsim_", with_stream=False)
         capi.declare(_hostsim, prefix="hostsim_wave_", with_stream=False)
+        for name, io in (("forward", capi.LossFwd), ("backward", capi.LossBwd)):
+            fn = getattr(_hostsim, "hostsim_row_kalman_loss_" + name)
+            fn.argtypes = [C.POINTER(capi.Dims), C.POINTER(io)]
+            fn.restype = C.c_int
     return _hostsim
 
 
@@ -41,8 +45,9 @@ class Backend:
     def __init__(self, kind):
         """kind: "hip" (product library; picks the lane- or wavefront-per-sequence
         kernels by dimension), "hostsim" (host build of the lane source) or
-        "hostsim_wave" (host build of the wavefront-per-sequence source)."""
-        assert kind in ("hip", "hostsim", "hostsim_wave")
+        "hostsim_wave" (host build of the wavefront-per-sequence source), "hostsim_row"
+        (host build of the 16-lanes-per-sequence source: fused objective only)."""
+        assert kind in ("hip", "hostsim", "hostsim_wave", "hostsim_row")
         self.kind = kind
         self.device = torch.device("cuda:0" if kind == "hip" else "cpu")
         self.lib = capi.load() if kind == "hip" else hostsim_lib()
@@ -223,6 +228,33 @@ class Backend:
         capi.fill(io, g_scale=g_scale, g_scale_stride=stride, **out)
         self._call("kalman_loss_backward", d, io, capi.OP_LOSS_BWD)
         out["_keep"] = g_scale
+        return out
+
+    def loss_value_and_grad(self, a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, weights, g_scale,
+                            stride, symmetrize=True, burn_in=0, want_terms=True):
+        """kvae_kalman_loss_value_and_grad: the outputs of both calls above from one call."""
+        assert self.kind == "hip"
+        T, B, p = a.shape
+        n, K = A_K.shape[1], A_K.shape[0]
+        dt = a.dtype
+        d = self.dims(T, B, n, p, K, dt, symmetrize, burn_in)
+        saved = self.new(self.lib.kvae_loss_saved_bytes(C.byref(d)) // a.element_size(), dtype=dt)
+        out = dict(out=self.new(4, dtype=dt))
+        if want_terms:
+            out["terms"] = self.new(3, T, B, dtype=dt)
+        grads = dict(d_a=self.new(T, B, p, dtype=dt), d_alpha=self.new(T + 1, B, K, dtype=dt),
+                     d_A_K=self.new(K, n, n, dtype=dt), d_C_K=self.new(K, p, n, dtype=dt),
+                     d_Q=self.new(n, n, dtype=dt), d_R=self.new(p, p, dtype=dt),
+                     d_m0=self.new(n, dtype=dt), d_P0=self.new(n, n, dtype=dt))
+        st = self.status()
+        io = capi.LossBwd()
+        capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m0=m0, P0=P0,
+                  eps=eps, saved=saved, status=st, **out)
+        io.fwd.w_obs, io.fwd.w_trans, io.fwd.w_post = weights
+        capi.fill(io, g_scale=g_scale, g_scale_stride=stride, **grads)
+        self._call("kalman_loss_value_and_grad", d, io, capi.OP_LOSS_VALUE_AND_GRAD)
+        out.update(grads)
+        out.update(status=st, _keep=(saved, g_scale))
         return out
 
     @staticmethod

@@ -21,11 +21,13 @@ def be():
     return Backend("hip")
 
 
-@pytest.fixture(params=["lane", "quad"], autouse=True)
+@pytest.fixture(params=["lane", "quad", "row"], autouse=True)
 def family(request):
-    """Run every case against both small-state kernel families (one lane or four lanes
-    per sequence; the library picks by batch size unless KVAE_SEQ_LANES forces one)."""
-    os.environ["KVAE_SEQ_LANES"] = "1" if request.param == "lane" else "4"
+    """Run every case against all three small-state kernel families (one, four or sixteen
+    lanes per sequence; the library picks by batch size unless KVAE_SEQ_LANES forces one;
+    where the sixteen-lane form does not exist -- float64, n = 8, T > 36 -- "row" runs the
+    library's own choice)."""
+    os.environ["KVAE_SEQ_LANES"] = {"lane": "1", "quad": "4", "row": "16"}[request.param]
     yield request.param
     os.environ.pop("KVAE_SEQ_LANES", None)
 
@@ -53,6 +55,13 @@ def test_loss_ragged_batches(be, B):
 def test_loss_short_sequences(be):
     KC.check_loss(be, T=1, B=5, n=4, p=2, K=3, dtype=torch.float64, seed=6)
     KC.check_loss(be, T=2, B=5, n=4, p=2, K=3, dtype=torch.float64, seed=7, burn_in=1)
+
+
+@pytest.mark.parametrize("n,p,K", [(4, 2, 3), (2, 1, 2), (3, 2, 2), (4, 2, 8)])
+def test_loss_row_form_full_lds(be, n, p, K):
+    """T = 36 is the longest sequence whose per-step state fits the 16-lane form's LDS."""
+    KC.check_loss(be, T=36, B=11, n=n, p=p, K=K, dtype=torch.float32, seed=31, burn_in=3,
+                  mask_kind="binary")
 
 
 def test_loss_long_sequence_f32(be):

@@ -88,6 +88,33 @@ def test_loss_f32_and_short_sequences(be):
     KC.check_loss(be, T=2, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=7, burn_in=1)
 
 
+# -- the same objective with one sequence over 16 lanes (kalman_row.h): the host build runs the
+# -- device source on an array of 16 lanes whose exchanges are permutations -------------
+@pytest.fixture(scope="module")
+def br():
+    return Backend("hostsim_row")
+
+
+@pytest.mark.parametrize("n,p,K", [(4, 2, 3), (2, 1, 2), (3, 2, 2), (4, 2, 8)])
+@pytest.mark.parametrize("mask_kind", ["none", "fractional"])
+def test_row_loss_f64(br, n, p, K, mask_kind):
+    KC.check_loss(br, T=6, B=3, n=n, p=p, K=K, dtype=torch.float64, seed=n + 2,
+                  mask_kind=mask_kind)
+
+
+@pytest.mark.parametrize("symmetrize,burn_in,stride", [(False, 0, 1), (True, 3, 0), (False, 2, 0),
+                                                       (True, 9, 1)])
+def test_row_loss_options(br, symmetrize, burn_in, stride):
+    KC.check_loss(br, T=7, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=13, mask_kind="binary",
+                  symmetrize=symmetrize, burn_in=burn_in, stride=stride)
+
+
+def test_row_loss_f32_and_short_sequences(br):
+    KC.check_loss(br, T=20, B=5, n=4, p=2, K=3, dtype=torch.float32, seed=6, burn_in=3)
+    KC.check_loss(br, T=1, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=6)
+    KC.check_loss(br, T=2, B=2, n=4, p=2, K=3, dtype=torch.float64, seed=7, burn_in=1)
+
+
 # -- wavefront-per-sequence source (kalman_wave.h), same checks ----------------
 WAVE_DIMS = [(4, 2, 3), (6, 3, 2), (16, 8, 4), (32, 16, 8)]
 

@@ -52,8 +52,15 @@ def main():
                                                         ws.data_ptr(), nb_f, stream))
         tb = timed(lambda: lib.kvae_kalman_loss_backward(C.byref(d), C.byref(io_b),
                                                          ws.data_ptr(), nb_b, stream))
+        nb_v = lib.kvae_workspace_bytes(C.byref(d), capi.OP_LOSS_VALUE_AND_GRAD)
+        ws_v = torch.empty(nb_v, dtype=torch.uint8, device="cuda")
+        tv = timed(lambda: lib.kvae_kalman_loss_value_and_grad(C.byref(d), C.byref(io_b),
+                                                               ws_v.data_ptr(), nb_v, stream))
         units = T * B
         flops = 5.6e3 * units
+        print(f"B={B} lanes={os.environ.get('KVAE_SEQ_LANES', 'auto')}: value_and_grad {tv:.1f} us"
+              f" = {units / tv * 1e6 / 1e9:.2f} G seq-steps/s,"
+              f" {flops / tv / 1e6 / 157.3 * 100:.1f} % of fp32 VALU peak", flush=True)
         print(f"B={B}: loss_forward {tf:.1f} us, loss_backward {tb:.1f} us, total {tf + tb:.1f} us"
               f" = {units / (tf + tb) * 1e6 / 1e9:.2f} G seq-steps/s,"
               f" {flops / (tf + tb) / 1e6 / 157.3 * 100:.1f} % of fp32 VALU peak", flush=True)
