@@ -472,24 +472,38 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         return u;
     };
 
+    // Everything a step reads from global memory (observations, weights, noise, mask) is
+    // independent of the recursion: every loop below requests the inputs of its next step
+    // before it works on the current one, so no memory latency sits in the serial chain.
+    auto clamp_t = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+
     // ---- phase F: filter, t = 0..T-1 -----------------------------------------------------
     {
-        V Pp = P0, mpc = m0c, mpr = m0r;
-        V w[K], wn[K];
-        weights(b, w);
-        for (int t = 0; t < T; ++t) {
+        struct In {
+            V wn[K], ar, mu;
+        };
+        auto load_in = [&](int t) {
+            In x;
             const long tb = (long)t * B + b;
-            weights(tb + B, wn);
-            const V ar = env.template vec_r<P>(f.a + tb * P);
+            weights(tb + B, x.wn);
+            x.ar = env.template vec_r<P>(f.a + tb * P);
+            x.mu = f.mask ? env.scalar(f.mask + tb) : V(R(1));
+            return x;
+        };
+        V Pp = P0, mpc = m0c, mpr = m0r;
+        V w[K];
+        weights(b, w);
+        In in = load_in(0);
+        for (int t = 0; t < T; ++t) {
+            const In nxt = load_in(clamp_t(t + 1));
             const V C = mix_row<V, K>(w, CK), Cs = mix_row<V, K>(w, CKs), CT = mix_row<V, K>(w, CKT);
-            const V An = mix_row<V, K>(wn, AK), Ans = mix_row<V, K>(wn, AKs),
-                    AnT = mix_row<V, K>(wn, AKT);
-            const Update u = update_terms_row(C, Cs, CT, mpc, Pp, ar, ST_NONPD_INNOVATION);
+            const V An = mix_row<V, K>(in.wn, AK), Ans = mix_row<V, K>(in.wn, AKs),
+                    AnT = mix_row<V, K>(in.wn, AKT);
+            const Update u = update_terms_row(C, Cs, CT, mpc, Pp, in.ar, ST_NONPD_INNOVATION);
             V Gr = qsum(u.G * u.rc), GM = mm(u.G, u.M);
             if (f.mask) {
-                const V mu = env.scalar(f.mask + tb);
-                Gr = mu * Gr;
-                GM = mu * GM;
+                Gr = in.mu * Gr;
+                GM = in.mu * GM;
             }
             const V mr = mpr + Gr, mc = r2c(mr);
             V Pf = Pp - GM;
@@ -504,7 +518,8 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             env.st_vec(t, SL::V_MN, mpc);
             env.st_mat(t, SL::M_PNEXT, Pn);
             KV_UNROLL
-            for (int k = 0; k < K; ++k) w[k] = wn[k];
+            for (int k = 0; k < K; ++k) w[k] = in.wn[k];
+            in = nxt;
         }
     }
     env.fence();
@@ -514,18 +529,29 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
     R* t_obs = f.terms;
     R* t_trans = f.terms ? f.terms + (long)T * B : nullptr;
     R* t_post = f.terms ? f.terms + 2 * (long)T * B : nullptr;
+    // inputs of smoother step t: weights of step t (C_t) and t+1 (A_{t+1}), noise, observation
+    struct InS {
+        V w[K], wn[K], ec, ar;
+    };
+    auto load_S = [&](int t) {
+        InS x;
+        const long tb = (long)t * B + b;
+        weights(tb, x.w);
+        weights(tb + B, x.wn);
+        x.ec = env.template vec_c<N>(f.eps + tb * N);
+        x.ar = env.template vec_r<P>(f.a + tb * P);
+        return x;
+    };
     // z_t = ms + chol(Ps) eps_t, obs_t, post_t (kalman_vae.py:165-168, 191-201, 236-238)
-    auto emit = [&](int t, V msr, V Ps, V& zc, V& zr) {
+    auto emit = [&](int t, const InS& in, V msr, V Ps, V& zc, V& zr) {
         const long tb = (long)t * B + b;
         const V L = cholesky_row<N>(Ps, st, ST_NONPD_SMOOTHED);
-        const V ec = env.template vec_c<N>(f.eps + tb * N);
-        zr = msr + qsum(L * ec);
+        zr = msr + qsum(L * in.ec);
         zc = r2c(zr);
-        const V post = (c_lat - half * qsum(ec * ec)) - rsum(vlog_masked<m_diag_lt(N)>(L));
-        V w[K];
-        weights(tb, w);
-        const V C = mix_row<V, K>(w, CK);
-        const V rr = env.template vec_r<P>(f.a + tb * P) - qsum(C * zc);
+        const V post =
+            (c_lat - half * qsum(in.ec * in.ec)) - rsum(vlog_masked<m_diag_lt(N)>(L));
+        const V C = mix_row<V, K>(in.w, CK);
+        const V rr = in.ar - qsum(C * zc);
         const V ur = qsum(Ri * r2c(rr));
         const V obs = (c_obs - half * csum(rr * ur)) - hlR;
         s_obs += obs;
@@ -543,12 +569,16 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         V msc = env.ld_vec_c(T - 1, SL::V_M), msr = env.ld_vec_r(T - 1, SL::V_M);
         V Ps = env.template ld_mat<L_NAT>(T - 1, SL::M_PFILT);
         V z1c, z1r;
-        emit(T - 1, msr, Ps, z1c, z1r);
+        InS in = load_S(T - 1);
+        {
+            const InS nxt = load_S(clamp_t(T - 2));
+            emit(T - 1, in, msr, Ps, z1c, z1r);
+            in = nxt;
+        }
         for (int t = T - 2; t >= 0; --t) {
             const long tb = (long)t * B + b;
-            V wn[K];
-            weights(tb + B, wn);
-            const V An = mix_row<V, K>(wn, AK), AnTs = mix_row<V, K>(wn, AKTs);
+            const InS nxt = load_S(clamp_t(t - 1));
+            const V An = mix_row<V, K>(in.wn, AK), AnTs = mix_row<V, K>(in.wn, AKTs);
             const V Pf = env.template ld_mat<L_NAT>(t, SL::M_PFILT);
             const V Pn = env.template ld_mat<L_NAT>(t, SL::M_PNEXT);
             const V mr = env.ld_vec_r(t, SL::V_M);
@@ -569,7 +599,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 env.st_mat(t, SL::M_PINV, Pi);
             }
             V zc, zr;
-            emit(t, msr, Ps, zc, zr);
+            emit(t, in, msr, Ps, zc, zr);
             // trans_{t+1} = log N(z_{t+1}; A_{t+1} z_t, Q)   (kalman_vae.py:209-229)
             const V rr = z1r - qsum(An * zc);
             const V ur = qsum(Qi * r2c(rr));
@@ -578,6 +608,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             if (t_trans) env.put_scalar(t_trans + tb + B, tr_);
             z1c = zc;
             z1r = zr;
+            in = nxt;
             env.fence();
         }
         // trans_0 = log N(z_0; m0, P0)
@@ -611,21 +642,35 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             V dA_row[K];
             KV_UNROLL
             for (int k = 0; k < K; ++k) dA_row[k] = zero;
-            V w[K], wn[K];
+            struct In {
+                V wn[K], ec, er, ar, ac;
+            };
+            auto load_in = [&](int t) {
+                In x;
+                const long tb = (long)t * B + b;
+                weights(tb + B, x.wn);
+                x.ec = env.template vec_c<N>(f.eps + tb * N);
+                x.er = env.template vec_r<N>(f.eps + tb * N);
+                x.ar = env.template vec_r<P>(f.a + tb * P);
+                x.ac = env.template vec_c<P>(f.a + tb * P);
+                return x;
+            };
+            V w[K];
             weights(b, w);
+            In in = load_in(0);
             for (int t = 0; t < T; ++t) {
                 const long tb = (long)t * B + b;
                 const bool last = t == T - 1;
-                weights(tb + B, wn);
+                const In nxt = load_in(clamp_t(t + 1));
+                const V* wn = in.wn;
                 const V C = mix_row<V, K>(w, CK), CT = mix_row<V, K>(w, CKT);
                 const V An = mix_row<V, K>(wn, AK), AnT = mix_row<V, K>(wn, AKT);
                 const V L = env.template ld_mat<L_NAT>(t, SL::M_L);
                 const V LT = env.template ld_mat<L_TRN>(t, SL::M_L);
-                const V ec = env.template vec_c<N>(f.eps + tb * N);
-                const V er = env.template vec_r<N>(f.eps + tb * N);
+                const V ec = in.ec, er = in.er;
                 // obs_t = log N(a_t; C_t z_t, R):  u = R^-1 (a - C z)
-                const V rr = env.template vec_r<P>(f.a + tb * P) - qsum(C * zc);
-                const V rc = env.template vec_c<P>(f.a + tb * P) - csum(CT * zr);
+                const V rr = in.ar - qsum(C * zc);
+                const V rc = in.ac - csum(CT * zr);
                 const V ur = qsum(Ri * rc), uc = csum(Ri * rr);
                 env.template put_vec_c<P>(g.d_a + tb * P, (-wo) * uc);
                 V Cb = wo * (ur * zc);
@@ -711,6 +756,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 utc = unc;
                 KV_UNROLL
                 for (int k = 0; k < K; ++k) w[k] = wn[k];
+                in = nxt;
                 env.fence();
             }
             // covariance gradients of the Gaussian terms: w/2 (sum u u^T - count Sigma^-1)
@@ -725,12 +771,31 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             V dwn[K];
             KV_UNROLL
             for (int k = 0; k < K; ++k) dwn[k] = zero;
+            // inputs of step t: weights of step t, observation, mask, and what phase SA left
+            // in d_alpha[t+1] and d_a[t]
+            struct In {
+                V w[K], ar, mu, da_old[K], a_old;
+            };
+            auto load_in = [&](int t) {
+                In x;
+                const long tb = (long)t * B + b;
+                weights(tb, x.w);
+                x.ar = env.template vec_r<P>(f.a + tb * P);
+                x.mu = f.mask ? env.scalar(f.mask + tb) : V(R(1));
+                KV_UNROLL
+                for (int k = 0; k < K; ++k)
+                    x.da_old[k] = t + 1 < T ? env.scalar(g.d_alpha + (tb + B) * K + k) : zero;
+                x.a_old = env.template vec_c<P>(g.d_a + tb * P);
+                return x;
+            };
+            V wn[K];
+            weights((long)T * B + b, wn);
+            In in = load_in(T - 1);
             for (int t = T - 1; t >= 0; --t) {
                 const long tb = (long)t * B + b;
-                V w[K], wn[K];
-                weights(tb, w);
-                weights(tb + B, wn);
-                const V ar = env.template vec_r<P>(f.a + tb * P);
+                const In nxt = load_in(clamp_t(t - 1));
+                const V* w = in.w;
+                const V ar = in.ar;
                 const V C = mix_row<V, K>(w, CK), Cs = mix_row<V, K>(w, CKs),
                         CT = mix_row<V, K>(w, CKT), CTs = mix_row<V, K>(w, CKTs);
                 const V An = mix_row<V, K>(wn, AK), Ans = mix_row<V, K>(wn, AKs),
@@ -767,8 +832,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                     // d_alpha[t+1] is complete here
                     KV_UNROLL
                     for (int k = 0; k < K; ++k) {
-                        V da = dwn[k] + rsum(Ab * AK[k]);
-                        if (t + 1 < T) da += env.scalar(g.d_alpha + (tb + B) * K + k);
+                        const V da = (dwn[k] + rsum(Ab * AK[k])) + in.da_old[k];
                         env.put_scalar(g.d_alpha + (tb + B) * K + k, da);
                         acc.AK[k] += wn[k] * Ab;
                     }
@@ -779,10 +843,9 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 const V H2 = sym ? half * H2s : Pb;
                 V mobc = mbc, mobr = mbr, Pob = H2;
                 if (f.mask) {
-                    const V mu = env.scalar(f.mask + tb);
-                    mobc = mu * mbc;
-                    mobr = mu * mbr;
-                    Pob = mu * H2;
+                    mobc = in.mu * mbc;
+                    mobr = in.mu * mbr;
+                    Pob = in.mu * H2;
                 }
                 mpbc = mbc;          // blend + identity term of m_obs
                 mpbr = mbr;
@@ -790,10 +853,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 const V GT = tr(u.G);
                 const V Gb = mobr * u.rc - mm(Pob, u.F);              // mob r^T - Pob M^T
                 const V rbc_ = csum(u.G * mobr), rbr = qsum(GT * mobc);   // G^T mob
-                {
-                    const V da = env.template vec_c<P>(g.d_a + tb * P) + rbc_;
-                    env.template put_vec_c<P>(g.d_a + tb * P, da);
-                }
+                env.template put_vec_c<P>(g.d_a + tb * P, in.a_old + rbc_);
                 V Cb = -(rbr * mpc);
                 mpbc -= csum(C * rbr);                                // C^T rb
                 mpbr -= qsum(CT * rbc_);
@@ -814,6 +874,9 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                     dwn[k] = rsum(Cb * CK[k]);
                     acc.CK[k] += w[k] * Cb;
                 }
+                KV_UNROLL
+                for (int k = 0; k < K; ++k) wn[k] = w[k];
+                in = nxt;
             }
             // d_alpha[0]: C-part of step 0 added to what phase SA wrote
             KV_UNROLL

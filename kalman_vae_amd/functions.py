@@ -526,13 +526,17 @@ class KalmanElboObjectiveFunction(torch.autograd.Function):
 
 
 class KalmanLossFunction(torch.autograd.Function):
-    """Filter -> smoother -> ELBO terms -> weighted totals as ONE autograd node and one
-    kernel launch per direction (kvae_kalman_loss_forward / _backward; the sequence of
-    kvae/kalman_vae.py:141-260 without an observation mask feeding the weight network):
+    """Filter -> smoother -> ELBO terms -> weighted totals as ONE autograd node (the sequence
+    of kvae/kalman_vae.py:141-260 without an observation mask feeding the weight network):
     (a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps; w_obs, w_trans, w_post) ->
     (objective, weighted totals (3,), terms (3,T,B) or an empty tensor).
-    None of the twelve filter / smoother tensors is materialised; the forward pass keeps
-    one opaque buffer of filtered / predicted / smoothed moments for the backward pass."""
+    None of the twelve filter / smoother tensors is materialised.
+
+    When a gradient will be asked for, the forward pass already computes it
+    (kvae_kalman_loss_value_and_grad: for a modest batch ONE launch whose per-step state never
+    leaves the chip) for a unit cotangent of the objective; the gradient is linear in that
+    cotangent, so the backward pass only multiplies.  A caller that differentiates the three
+    weighted totals separately gets kvae_kalman_loss_backward with its cotangents instead."""
 
     @staticmethod
     def forward(ctx, a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, w_obs, w_trans, w_post,
@@ -555,15 +559,35 @@ class KalmanLossFunction(torch.autograd.Function):
                             device=a.device)
         terms = new(3, T, B) if want_terms else None
         out = new(4)
-        io = capi.fill(capi.LossFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R,
-                       m0=m0, P0=P0, eps=eps, saved=saved, terms=terms, out=out,
-                       status=status_word(a.device))
-        io.w_obs, io.w_trans, io.w_post = float(w_obs), float(w_trans), float(w_post)
-        ws, nbytes = _workspace(dims, capi.OP_LOSS_FWD, a.device)
-        capi.check(lib.kvae_kalman_loss_forward(C.byref(dims), C.byref(io), ws.data_ptr(), nbytes,
-                                                capi.current_stream_ptr()))
-        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, saved)
+        need = ctx.needs_input_grad
+        with_grad = any(need[:10])
         ctx.dims, ctx.weights = dims, (float(w_obs), float(w_trans), float(w_post))
+        if with_grad:
+            grads = dict(d_a=new(T, B, p), d_alpha=new(T + 1, B, K), d_A_K=new(K, n, n),
+                         d_C_K=new(K, p, n), d_Q=new(n, n), d_R=new(p, p),
+                         d_m0=new(n) if need[7] else None, d_P0=new(n, n) if need[8] else None)
+            io = capi.LossBwd()
+            capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m0=m0,
+                      P0=P0, eps=eps, saved=saved, terms=terms, out=out,
+                      status=status_word(a.device))
+            io.fwd.w_obs, io.fwd.w_trans, io.fwd.w_post = ctx.weights
+            unit = _unit_cotangent(a)
+            capi.fill(io, g_scale=unit, g_scale_stride=0, **grads)
+            ws, nbytes = _workspace(dims, capi.OP_LOSS_VALUE_AND_GRAD, a.device)
+            capi.check(lib.kvae_kalman_loss_value_and_grad(C.byref(dims), C.byref(io),
+                                                           ws.data_ptr(), nbytes,
+                                                           capi.current_stream_ptr()))
+            ctx.unit_grads = grads
+        else:
+            io = capi.fill(capi.LossFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q,
+                           R=R, m0=m0, P0=P0, eps=eps, saved=saved, terms=terms, out=out,
+                           status=status_word(a.device))
+            io.w_obs, io.w_trans, io.w_post = ctx.weights
+            ws, nbytes = _workspace(dims, capi.OP_LOSS_FWD, a.device)
+            capi.check(lib.kvae_kalman_loss_forward(C.byref(dims), C.byref(io), ws.data_ptr(),
+                                                    nbytes, capi.current_stream_ptr()))
+            ctx.unit_grads = None
+        ctx.save_for_backward(a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, saved)
         ctx.set_materialize_grads(False)
         if terms is None:
             terms = a.new_empty(0)
@@ -575,6 +599,15 @@ class KalmanLossFunction(torch.autograd.Function):
         if g_objective is None and g_weighted is None:
             return (None,) * 16
         a, alpha, mask, A_K, C_K, Q, R, m0, P0, eps, saved = ctx.saved_tensors
+        if g_weighted is None and ctx.unit_grads is not None:
+            # the usual case: only the objective was differentiated
+            g = ctx.unit_grads
+            ctx.unit_grads = None
+            names = ("d_a", "d_alpha", "d_A_K", "d_C_K", "d_Q", "d_R", "d_m0", "d_P0")
+            present = [g[k] for k in names if g[k] is not None]
+            torch._foreach_mul_(present, g_objective.reshape(()))
+            return (g["d_a"], g["d_alpha"], None, g["d_A_K"], g["d_C_K"], g["d_Q"], g["d_R"],
+                    g["d_m0"], g["d_P0"], None, None, None, None, None, None, None)
         if g_weighted is None:
             scale, stride = g_objective.contiguous(), 0
         else:
@@ -599,6 +632,18 @@ class KalmanLossFunction(torch.autograd.Function):
                                                          nbytes, capi.current_stream_ptr()))
         return (d_a, d_alpha, None, d_A_K, d_C_K, d_Q, d_R, d_m0, d_P0, None, None, None, None,
                 None, None, None)
+
+
+_unit = {}
+
+
+def _unit_cotangent(like):
+    """A device scalar 1 of ``like``'s dtype (cached per device: no fill launch per step)."""
+    key = (like.device, like.dtype)
+    t = _unit.get(key)
+    if t is None:
+        t = _unit[key] = torch.ones(1, dtype=like.dtype, device=like.device)
+    return t
 
 
 def _shift_totals(objective, weighted, terms, count, shifts, like):

@@ -11,7 +11,9 @@ for path in sys.argv[1:]:
         name = r["Kernel_Name"]
         if "kvae::" not in name:
             continue
-        short = name.split("kvae::")[1].split("<")[0]
+        short = name.split("kvae::")[1].split("(")[0]
+        if "loss_row_kernel" not in short:      # the row kernels differ by template arguments
+            short = short.split("<")[0]
         vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in vals.items():
     print(k, {n: sorted(v)[len(v) // 2] for n, v in c.items()})
