@@ -6,12 +6,19 @@
 // four lanes per sequence (kalman_loss_quad.h) leave three quarters of the SIMDs without
 // work and one lane per sequence (kalman_loss.h) all but 64 of them.
 //
-//   * products: C = X Y = sum_d X[i][(i+d)%4] Y[(i+d)%4][j]; the second factor is Y rotated
-//     by 4 d lanes (row_ror), the first the quad broadcast of lane d of X "skewed"
+//   * products: C[i][j] = sum_k X[i][k] y_k[j] is four multiply-adds whose first factor is
+//     the quad broadcast of lane k of X (a DPP operand of the multiply-add itself) and whose
+//     second factor y_k is row k of the right operand as seen from column j.  For an operand
+//     that lives in LDS (every matrix a later phase reads again does) all four y_k are ONE
+//     16-byte read of a row or column: no rotation, no transposition.  For an operand that
+//     exists only in registers they are Y rotated by 4 k lanes (row_ror) against X "skewed"
 //     (row i rotated left by i: three bank-masked quad_perm moves);
 //   * X v and X^T v are one multiply and two DPP additions (over the quad / across quads);
 //     vectors live either as v[j] in every quad ("c") or as v[i] in every lane of quad i ("r");
-//   * the SPD inverse is the symmetric sweep operator (one pivot per step, everything
+//   * everything of the observation's size p <= 2 (C_t, the gain, the innovation covariance
+//     and their adjoints) is kept as p vectors and p x p replicated scalars, so their
+//     "products" are matrix-vector and outer products and the p x p inverse is closed form;
+//   * the n x n SPD inverse is the symmetric sweep operator (one pivot per step, everything
 //     element-parallel), the Cholesky factor a right-looking factorisation;
 //   * smaller n, p are zero / identity padded to 4: the padding block stays exactly
 //     decoupled (block-diagonal operands), contributes log 1 = 0 and 0^2 to every term, and
@@ -43,6 +50,12 @@ namespace row {
 #define KR_FN __device__ __forceinline__
 #else
 #define KR_FN inline
+#endif
+
+// Timing experiments only (tools/exp/build_row_variants.sh): a build that returns after
+// phase F (1), S (2) or SA (3) of a sequence; the shipped library runs all four.
+#ifndef KR_STOP_AFTER
+#define KR_STOP_AFTER 4
 #endif
 
 template <int I, int N, typename F>
@@ -205,6 +218,17 @@ inline Row<R> guard_pivot(const Row<R>& x, int& st, int bit) {
     return r;
 }
 
+// four values per lane: the rows (or columns) of a right operand as one column sees them
+template <typename V>
+struct Q4 {
+    V v[4];
+};
+// C(i, j) = sum_k X(i, k) y.v[k](i, j)
+template <typename R>
+inline Row<R> mm4(const Row<R>& X, const Q4<Row<R>>& y) {
+    return (qb<0>(X) * y.v[0] + qb<1>(X) * y.v[1]) + (qb<2>(X) * y.v[2] + qb<3>(X) * y.v[3]);
+}
+
 // =========================================================================================
 // Device value type: float, the element of this lane.
 // =========================================================================================
@@ -272,6 +296,23 @@ KR_FN float guard_pivot(float x, int& st, int bit) {
     st |= ok ? 0 : bit;
     return ok ? x : 1.f;
 }
+// The product core.  The compiler does not fold a DPP exchange into a multiply-add (it forms
+// v_fmac_f32 only after its DPP pass has run) and spends a move per term, so the four
+// instructions are written out.  A DPP operand must have been written at least two wait
+// states earlier and the compiler cannot see that this statement reads X that way, nor that
+// the next statement may read the result that way: hence the s_nop on either side.
+KR_FN float mm4(float X, const Q4<float>& y) {
+    float acc;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "=&v"(acc)
+        : "v"(X), "v"(y.v[0]), "v"(y.v[1]), "v"(y.v[2]), "v"(y.v[3]));
+    return acc;
+}
 #endif  // __HIPCC__
 
 // =========================================================================================
@@ -284,15 +325,19 @@ KR_FN V r2c(V xr) { return csum(sel<M_DIAG>(xr, V(0))); }   // v[i] per quad -> 
 template <typename V>
 KR_FN V c2r(V xc) { return qsum(sel<M_DIAG>(xc, V(0))); }
 
-// X Y from X skewed and the four rotations of Y
+// the rows of a register operand as the columns see them: Y rotated by 0, 4, 8, 12 lanes.
+// mm4(skew(X), rots(Y)) = X Y.
 template <typename V>
-KR_FN V mm_sr(V Xs, V Y0, V Y1, V Y2, V Y3) {
-    return (qb<0>(Xs) * Y0 + qb<1>(Xs) * Y1) + (qb<2>(Xs) * Y2 + qb<3>(Xs) * Y3);
+KR_FN Q4<V> rots(V Y) {
+    Q4<V> q;
+    q.v[0] = Y;
+    q.v[1] = rot<1>(Y);
+    q.v[2] = rot<2>(Y);
+    q.v[3] = rot<3>(Y);
+    return q;
 }
 template <typename V>
-KR_FN V mm_s(V Xs, V Y) { return mm_sr(Xs, Y, rot<1>(Y), rot<2>(Y), rot<3>(Y)); }
-template <typename V>
-KR_FN V mm(V X, V Y) { return mm_s(skew(X), Y); }
+KR_FN V mm(V X, V Y) { return mm4(skew(X), rots(Y)); }
 template <typename V>
 KR_FN V symm(V X) {
     using S = typename scalar_of<V>::type;
@@ -343,8 +388,9 @@ KR_FN V cholesky_row(V X, int& st, int bit) {
 
 // (L^-1)^T for the leading DIM x DIM block of a lower-triangular L (identity elsewhere):
 // columns of X = U^-1, U = L^T, left to right:  X[:,k] = (e_k - sum_{q<k} X[:,q] U[q][k]) / U[k][k].
-template <int DIM, typename V>
-KR_FN V tri_inverse_t(V L) {
+// colc(k) supplies L[j][k] in lane (i, j) (row k of U as the columns see it).
+template <int DIM, typename V, typename ColC>
+KR_FN V tri_inverse_t(V L, ColC&& colc) {
     using S = typename scalar_of<V>::type;
     const V eye = sel<M_DIAG>(V(S(1)), V(S(0)));
     V rest = eye, X = eye;
@@ -352,16 +398,40 @@ KR_FN V tri_inverse_t(V L) {
         constexpr int k = decltype(kc)::value;
         const V inv = vrcp(rbc<5 * k>(L));
         X = sel<m_col(k)>(rest * inv, X);
-        const V colc = r2c(qb<k>(L));     // L[j][k] = U[k][j]
-        rest = rest - qb<k>(X) * colc;
+        if constexpr (k + 1 < DIM) rest = rest - qb<k>(X) * colc(kc);
     });
     return X;
+}
+
+// Inverse and half log-determinant of a symmetric positive definite P x P matrix of
+// replicated scalars, P <= 2, in closed form.  S and Si are indexed [k][l]; only k <= l of S
+// is read.
+template <int P, typename V>
+KR_FN void small_spd_inverse(const V (*S)[P], V (*Si)[P], V& hl, int& st, int bit) {
+    using Sc = typename scalar_of<V>::type;
+    static_assert(P == 1 || P == 2, "observation dimension of the 16-lane form is 1 or 2");
+    if constexpr (P == 1) {
+        const V d = guard_pivot(S[0][0], st, bit);
+        Si[0][0] = vrcp(d);
+        hl = Sc(0.5) * vlog_masked<M_ALL>(d);
+    } else {
+        const V d0 = guard_pivot(S[0][0], st, bit);
+        const V det = guard_pivot(d0 * S[1][1] - S[0][1] * S[0][1], st, bit);
+        const V r = vrcp(det);
+        Si[0][0] = S[1][1] * r;
+        Si[0][1] = Si[1][0] = -(S[0][1] * r);
+        Si[1][1] = d0 * r;
+        hl = Sc(0.5) * vlog_masked<M_ALL>(det);
+    }
 }
 
 // =========================================================================================
 // Per-step state in LDS (float offsets inside one sequence-step; a matrix is 16 floats,
 // a vector 4).  The adjoint phases overwrite slots the forward phases no longer need.
+// Behind the T steps there are SCRATCH matrix slots per sequence that belong to no step:
+// operands that exist only in registers are bounced through them to be read as rows.
 // =========================================================================================
+constexpr int SCRATCH = 5;
 template <bool GRAD>
 struct Slots;
 template <>
@@ -381,20 +451,26 @@ struct Slots<false> {
 };
 
 // running sums of the parameter gradients of one sequence (device: of this lane)
-template <typename V, int K>
+template <typename V, int P, int K>
 struct RowAcc {
-    V AK[K];    // d A_K[k], natural layout
-    V AKT[K];   // a second part of d A_K[k], transposed layout
-    V CK[K];
-    V Q, Rm, P0;
-    V m0c;      // d m0 as v[j]
+    V AK[K];       // d A_K[k], natural layout
+    V AKT[K];      // a second part of d A_K[k], transposed layout
+    V CKc[K][P];   // row r of d C_K[k] as v[j]
+    V Q, P0;
+    V m0c;         // d m0 as v[j]
+    V Rs[P][P];    // d R, replicated scalars
 };
-template <typename V, int K>
-KR_FN void zero_acc(RowAcc<V, K>& a) {
+template <typename V, int P, int K>
+KR_FN void zero_acc(RowAcc<V, P, K>& a) {
     using S = typename scalar_of<V>::type;
     const V z = V(S(0));
-    for (int k = 0; k < K; ++k) a.AK[k] = a.AKT[k] = a.CK[k] = z;
-    a.Q = a.Rm = a.P0 = a.m0c = z;
+    for (int k = 0; k < K; ++k) {
+        a.AK[k] = a.AKT[k] = z;
+        for (int r = 0; r < P; ++r) a.CKc[k][r] = z;
+    }
+    a.Q = a.P0 = a.m0c = z;
+    for (int r = 0; r < P; ++r)
+        for (int c = 0; c < P; ++c) a.Rs[r][c] = z;
 }
 
 template <typename V, int K>
@@ -404,6 +480,17 @@ KR_FN V mix_row(const V* w, const V* bases) {
     for (int k = 1; k < K; ++k) acc = acc + w[k] * bases[k];
     return acc;
 }
+// row r of sum_k w[k] C_K[k] from bases[k][r]
+template <typename V, int P, int K>
+KR_FN void mix_rows(const V* w, const V (*bases)[P], V* out) {
+    KV_UNROLL
+    for (int r = 0; r < P; ++r) {
+        V acc = w[0] * bases[0][r];
+        KV_UNROLL
+        for (int k = 1; k < K; ++k) acc = acc + w[k] * bases[k][r];
+        out[r] = acc;
+    }
+}
 
 // =========================================================================================
 // One sequence: filter -> smoother -> terms (-> adjoint).
@@ -412,63 +499,101 @@ KR_FN V mix_row(const V* w, const V* bases) {
 //   scalar(p)                      *p in every lane
 //   vec_c<LEN>(p) / vec_r<LEN>(p)  p[j] / p[i], zero beyond LEN
 //   mat<ROWS, COLS, LAYOUT, PAD>(p) row-major ROWS x COLS matrix, zero (PAD: identity) padded
-//   put_scalar(p, x), put_vec_c<LEN>(p, xc)              (nothing for an inactive sequence)
-//   st_mat / ld_mat<LAYOUT> / st_vec / ld_vec_c / ld_vec_r (t, slot)   the LDS state
+//   put_scalar(p, x)               (nothing for an inactive sequence)
+//   at_mat(t, slot) / at_vec(t, slot) / scr(i)   a place in the LDS state / scratch
+//   st_mat, st_mat_t (transposed), ld_mat, ld_mat_t, ld_rows4 (lane (i, j): row j),
+//   ld_cols4 (column j), ld_colc<k> (element [j][k]), st_vec, ld_vec_c, ld_vec_r
 //   fence()                        orders the LDS accesses of the lanes of the sequence
 // sums[0..2] += obs, trans, post of the sequence (value in every lane).
 // =========================================================================================
-template <typename V, typename R, int N, int P, int K, bool GRAD, typename Env>
+template <typename V, typename R, int N, int P, int K, bool GRAD, bool SYM, typename Env>
 KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
-                             RowAcc<V, K>& acc, int& st) {
+                             RowAcc<V, P, K>& acc, int& st) {
     using SL = Slots<GRAD>;
     const LossFwdArgs<R>& f = g.f;
     const long B = f.B;
     const int T = f.T;
-    const bool sym = f.symmetrize != 0;
+    constexpr bool sym = SYM;   // symmetrize_covariance: compiled in, the loop bodies stay straight-line
     const R half = R(0.5);
     const V zero = V(R(0));
 
     // ---- constants of the call -------------------------------------------------------
     const V Q = env.template mat<N, N, L_NAT, true>(f.Q);
-    const V Rm = env.template mat<P, P, L_NAT, true>(f.Rm);
     const V P0 = env.template mat<N, N, L_NAT, true>(f.P0);
     const V m0c = env.template vec_c<N>(f.m0), m0r = env.template vec_r<N>(f.m0);
     V hlR, hlQ, hl0;
-    const V Ri = spd_inverse<P>(Rm, hlR, st, ST_NONPD_NOISE);
     const V Qi = spd_inverse<N>(Q, hlQ, st, ST_NONPD_NOISE);
     const V P0i = spd_inverse<N>(P0, hl0, st, ST_NONPD_NOISE);
-    V AK[K], AKs[K], AKT[K], AKTs[K], CK[K], CKs[K], CKT[K], CKTs[K];
+    V Rs[P][P], Ri[P][P];
+    KV_UNROLL
+    for (int r = 0; r < P; ++r) {
+        KV_UNROLL
+        for (int c = 0; c < P; ++c) Rs[r][c] = env.scalar(f.Rm + r * P + c);
+    }
+    small_spd_inverse<P, V>(Rs, Ri, hlR, st, ST_NONPD_NOISE);
+    V AK[K], AKs[K], AKT[K], AKTs[K], CKc[K][P], CKr[K][P];
     KV_UNROLL
     for (int k = 0; k < K; ++k) {
         AK[k] = env.template mat<N, N, L_NAT, false>(f.A_K + k * N * N);
         AKs[k] = env.template mat<N, N, L_SKEW, false>(f.A_K + k * N * N);
         AKT[k] = env.template mat<N, N, L_TRN, false>(f.A_K + k * N * N);
         AKTs[k] = env.template mat<N, N, L_TSKEW, false>(f.A_K + k * N * N);
-        CK[k] = env.template mat<P, N, L_NAT, false>(f.C_K + k * P * N);
-        CKs[k] = env.template mat<P, N, L_SKEW, false>(f.C_K + k * P * N);
-        CKT[k] = env.template mat<P, N, L_TRN, false>(f.C_K + k * P * N);
-        if (GRAD) CKTs[k] = env.template mat<P, N, L_TSKEW, false>(f.C_K + k * P * N);
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) {
+            CKc[k][r] = env.template vec_c<N>(f.C_K + (k * P + r) * N);
+            CKr[k][r] = env.template vec_r<N>(f.C_K + (k * P + r) * N);
+        }
     }
     const R c_obs = R(-0.5) * R(P) * log_2pi<R>(), c_lat = R(-0.5) * R(N) * log_2pi<R>();
     auto weights = [&](long tb, V* w) {
         KV_UNROLL
         for (int k = 0; k < K; ++k) w[k] = env.scalar(f.alpha + tb * K + k);
     };
-
-    // Quantities of one measurement update (state_space_model.py:291-311), from the
-    // prediction (mp, Pp) and C in three layouts.
-    struct Update {
-        V M, F, Si, G, rr, rc;
+    auto observation = [&](long tb, V* a) {
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) a[r] = env.scalar(f.a + tb * P + r);
     };
-    auto update_terms_row = [&](V C, V Cs, V CT, V mpc, V Pp, V ar, int bit) {
+    // sum_r x[r] y[r]
+    auto dotp = [&](const V* x, const V* y) {
+        V s = x[0] * y[0];
+        KV_UNROLL
+        for (int r = 1; r < P; ++r) s = s + x[r] * y[r];
+        return s;
+    };
+
+    // Quantities of one measurement update (state_space_model.py:291-311) from the
+    // prediction (mp, Pp) and the rows of C as v[j] (cc) and v[i] (cr):
+    //   fc[r] = row r of M = C Pp,  fr[r] = column r of F = Pp C^T (as v[j] / v[i]),
+    //   Si = (C Pp C^T + R)^-1,  gr / gc[r] = column r of the gain F Si,  r = a - C mp.
+    struct Update {
+        V fr[P], fc[P], Si[P][P], gr[P], gc[P], r[P];
+    };
+    auto update_terms_row = [&](const V* cc, const V* cr, V mpc, V Pp, const V* a, int bit) {
         Update u;
-        u.M = mm_s(Cs, Pp);                 // C Pp
-        u.F = mm(Pp, CT);                   // Pp C^T
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) {
+            u.fr[r] = qsum(Pp * cc[r]);
+            u.fc[r] = csum(Pp * cr[r]);
+        }
+        V S[P][P];
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) {
+            KV_UNROLL
+            for (int c = r; c < P; ++c) S[r][c] = qsum(u.fc[r] * cc[c]) + Rs[r][c];
+        }
         V hl;
-        u.Si = spd_inverse<P>(mm_s(Cs, u.F) + Rm, hl, st, bit);
-        u.G = mm(u.F, u.Si);
-        u.rr = ar - qsum(C * mpc);          // innovation a - C mp
-        u.rc = r2c(u.rr);
+        small_spd_inverse<P, V>(S, u.Si, hl, st, bit);
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) {
+            u.gr[r] = u.fr[0] * u.Si[0][r];
+            u.gc[r] = u.fc[0] * u.Si[0][r];
+            KV_UNROLL
+            for (int c = 1; c < P; ++c) {
+                u.gr[r] = u.gr[r] + u.fr[c] * u.Si[c][r];
+                u.gc[r] = u.gc[r] + u.fc[c] * u.Si[c][r];
+            }
+            u.r[r] = a[r] - qsum(cc[r] * mpc);
+        }
         return u;
     };
 
@@ -480,13 +605,13 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
     // ---- phase F: filter, t = 0..T-1 -----------------------------------------------------
     {
         struct In {
-            V wn[K], ar, mu;
+            V wn[K], a[P], mu;
         };
         auto load_in = [&](int t) {
             In x;
             const long tb = (long)t * B + b;
             weights(tb + B, x.wn);
-            x.ar = env.template vec_r<P>(f.a + tb * P);
+            observation(tb, x.a);
             x.mu = f.mask ? env.scalar(f.mask + tb) : V(R(1));
             return x;
         };
@@ -496,34 +621,42 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         In in = load_in(0);
         for (int t = 0; t < T; ++t) {
             const In nxt = load_in(clamp_t(t + 1));
-            const V C = mix_row<V, K>(w, CK), Cs = mix_row<V, K>(w, CKs), CT = mix_row<V, K>(w, CKT);
+            V cc[P], cr[P];
+            mix_rows<V, P, K>(w, CKc, cc);
+            mix_rows<V, P, K>(w, CKr, cr);
             const V An = mix_row<V, K>(in.wn, AK), Ans = mix_row<V, K>(in.wn, AKs),
                     AnT = mix_row<V, K>(in.wn, AKT);
-            const Update u = update_terms_row(C, Cs, CT, mpc, Pp, in.ar, ST_NONPD_INNOVATION);
-            V Gr = qsum(u.G * u.rc), GM = mm(u.G, u.M);
-            if (f.mask) {
-                Gr = in.mu * Gr;
-                GM = in.mu * GM;
+            env.st_mat(env.scr(0), An);               // read back as rows: X An^T
+            const Update u = update_terms_row(cc, cr, mpc, Pp, in.a, ST_NONPD_INNOVATION);
+            V Grr = u.gr[0] * u.r[0], Grc = u.gc[0] * u.r[0];
+            // G M = F Si F^T is symmetric: its symmetric part directly, without a transposition
+            V GM = sym ? u.gr[0] * u.fc[0] + u.gc[0] * u.fr[0] : u.gr[0] * u.fc[0];
+            KV_UNROLL
+            for (int r = 1; r < P; ++r) {
+                Grr = Grr + u.gr[r] * u.r[r];
+                Grc = Grc + u.gc[r] * u.r[r];
+                GM = GM + (sym ? u.gr[r] * u.fc[r] + u.gc[r] * u.fr[r] : u.gr[r] * u.fc[r]);
             }
-            const V mr = mpr + Gr, mc = r2c(mr);
-            V Pf = Pp - GM;
-            if (sym) Pf = symm(Pf);
-            V Pn = mm(mm_s(Ans, Pf), AnT) + Q;          // An Pf An^T + Q
+            const V mus = sym ? half * in.mu : in.mu;       // mask weight (1 without a mask)
+            const V mr = mpr + in.mu * Grr, mc = mpc + in.mu * Grc;
+            const V Pf = Pp - mus * GM;
+            V Pn = mm4(mm4(Ans, rots(Pf)), env.ld_rows4(env.scr(0))) + Q;   // An Pf An^T + Q
             if (sym) Pn = symm(Pn);
             mpr = qsum(An * mc);
             mpc = csum(AnT * mr);
             Pp = Pn;
-            env.st_vec(t, SL::V_M, mc);
-            env.st_mat(t, SL::M_PFILT, Pf);
-            env.st_vec(t, SL::V_MN, mpc);
-            env.st_mat(t, SL::M_PNEXT, Pn);
+            env.st_vec(env.at_vec(t, SL::V_M), mc);
+            env.st_mat(env.at_mat(t, SL::M_PFILT), Pf);
+            env.st_vec(env.at_vec(t, SL::V_MN), mpc);
+            env.st_mat(env.at_mat(t, SL::M_PNEXT), Pn);
             KV_UNROLL
             for (int k = 0; k < K; ++k) w[k] = in.wn[k];
             in = nxt;
+            env.fence();
         }
     }
-    env.fence();
 
+    if (KR_STOP_AFTER < 2) return;
     // ---- phase S: smoother and terms, t = T-1..0 -------------------------------------------
     V s_obs = zero, s_trans = zero, s_post = zero;
     R* t_obs = f.terms;
@@ -531,7 +664,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
     R* t_post = f.terms ? f.terms + 2 * (long)T * B : nullptr;
     // inputs of smoother step t: weights of step t (C_t) and t+1 (A_{t+1}), noise, observation
     struct InS {
-        V w[K], wn[K], ec, ar;
+        V w[K], wn[K], ec, a[P];
     };
     auto load_S = [&](int t) {
         InS x;
@@ -539,9 +672,12 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         weights(tb, x.w);
         weights(tb + B, x.wn);
         x.ec = env.template vec_c<N>(f.eps + tb * N);
-        x.ar = env.template vec_r<P>(f.a + tb * P);
+        observation(tb, x.a);
         return x;
     };
+    // log N(x; mean, Sigma) from the residual in both forms and Sigma^-1: the quadratic form is
+    // the sum of rr[i] Si[i][j] rc[j] over the 16 lanes
+    auto gauss = [&](V rr, V rc, V Si, V hl) { return (c_lat - half * rsum(Si * rr * rc)) - hl; };
     // z_t = ms + chol(Ps) eps_t, obs_t, post_t (kalman_vae.py:165-168, 191-201, 236-238)
     auto emit = [&](int t, const InS& in, V msr, V Ps, V& zc, V& zr) {
         const long tb = (long)t * B + b;
@@ -550,10 +686,13 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         zc = r2c(zr);
         const V post =
             (c_lat - half * qsum(in.ec * in.ec)) - rsum(vlog_masked<m_diag_lt(N)>(L));
-        const V C = mix_row<V, K>(in.w, CK);
-        const V rr = in.ar - qsum(C * zc);
-        const V ur = qsum(Ri * r2c(rr));
-        const V obs = (c_obs - half * csum(rr * ur)) - hlR;
+        V cc[P], res[P], u[P];
+        mix_rows<V, P, K>(in.w, CKc, cc);
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) res[r] = in.a[r] - qsum(cc[r] * zc);
+        KV_UNROLL
+        for (int r = 0; r < P; ++r) u[r] = dotp(Ri[r], res);
+        const V obs = (c_obs - half * dotp(res, u)) - hlR;
         s_obs += obs;
         s_post += post;
         if (t_obs) {
@@ -561,13 +700,13 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             env.put_scalar(t_post + tb, post);
         }
         if (GRAD) {
-            env.st_vec(t, SL::V_Z, zc);
-            env.st_mat(t, SL::M_L, L);
+            env.st_vec(env.at_vec(t, SL::V_Z), zc);
+            env.st_mat(env.at_mat(t, SL::M_L), L);
         }
     };
     {
-        V msc = env.ld_vec_c(T - 1, SL::V_M), msr = env.ld_vec_r(T - 1, SL::V_M);
-        V Ps = env.template ld_mat<L_NAT>(T - 1, SL::M_PFILT);
+        V msc = env.ld_vec_c(env.at_vec(T - 1, SL::V_M)), msr = env.ld_vec_r(env.at_vec(T - 1, SL::V_M));
+        V Ps = env.ld_mat(env.at_mat(T - 1, SL::M_PFILT));
         V z1c, z1r;
         InS in = load_S(T - 1);
         {
@@ -578,32 +717,38 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
         for (int t = T - 2; t >= 0; --t) {
             const long tb = (long)t * B + b;
             const InS nxt = load_S(clamp_t(t - 1));
-            const V An = mix_row<V, K>(in.wn, AK), AnTs = mix_row<V, K>(in.wn, AKTs);
-            const V Pf = env.template ld_mat<L_NAT>(t, SL::M_PFILT);
-            const V Pn = env.template ld_mat<L_NAT>(t, SL::M_PNEXT);
-            const V mr = env.ld_vec_r(t, SL::V_M);
-            const V mnc = env.ld_vec_c(t, SL::V_MN);
-            V hl;
-            const V Pi = spd_inverse<N>(Pn, hl, st, ST_NONPD_PREDICTED);
-            const V J = mm(Pf, mm_s(AnTs, Pi));          // Pf An^T Pn^-1
+            // what the adjoint reads again stays with its step, else in a scratch slot
+            const auto locPi = GRAD ? env.at_mat(t, SL::M_PINV) : env.scr(1);
+            const auto locJ = GRAD ? env.at_mat(t, SL::M_J) : env.scr(2);
+            const auto locD = GRAD ? env.at_mat(t, SL::M_D) : env.scr(3);
+            const V An = mix_row<V, K>(in.wn, AK), AnT = mix_row<V, K>(in.wn, AKT);
+            const V Pf = env.ld_mat(env.at_mat(t, SL::M_PFILT));
+            const V Pn = env.ld_mat(env.at_mat(t, SL::M_PNEXT));
+            const V mr = env.ld_vec_r(env.at_vec(t, SL::V_M));
+            const V mnc = env.ld_vec_c(env.at_vec(t, SL::V_MN));
             const V dc = msc - mnc;
             const V D = Ps - Pn;
+            if (GRAD) {
+                env.st_mat(locD, D);
+                env.st_vec(env.at_vec(t, SL::V_D), dc);
+            }
+            V hl;
+            const V Pi = spd_inverse<N>(Pn, hl, st, ST_NONPD_PREDICTED);
+            if (GRAD) env.st_mat(locPi, Pi);
+            // (operands that have just been computed go through lane rotations, not LDS: a
+            // round trip there would sit in the serial chain)
+            const V W = mm4(mix_row<V, K>(in.wn, AKTs), rots(Pi));   // An^T Pn^-1
+            const V J = mm4(skew(Pf), rots(W));               // Pf W
+            env.st_mat(locJ, J);
             msr = mr + qsum(J * dc);
             msc = r2c(msr);
-            Ps = Pf + mm(J, tr(mm(J, D)));               // Pf + J D J^T  (D symmetric)
+            const V JD = mm4(skew(J), rots(D));               // J D
+            Ps = Pf + mm4(JD, env.ld_rows4(locJ));            // + (J D) J^T
             if (sym) Ps = symm(Ps);
-            if (GRAD) {
-                env.st_vec(t, SL::V_D, dc);
-                env.st_mat(t, SL::M_D, D);
-                env.st_mat(t, SL::M_J, J);
-                env.st_mat(t, SL::M_PINV, Pi);
-            }
             V zc, zr;
             emit(t, in, msr, Ps, zc, zr);
             // trans_{t+1} = log N(z_{t+1}; A_{t+1} z_t, Q)   (kalman_vae.py:209-229)
-            const V rr = z1r - qsum(An * zc);
-            const V ur = qsum(Qi * r2c(rr));
-            const V tr_ = (c_lat - half * csum(rr * ur)) - hlQ;
+            const V tr_ = gauss(z1r - qsum(An * zc), z1c - csum(AnT * zr), Qi, hlQ);
             s_trans += tr_;
             if (t_trans) env.put_scalar(t_trans + tb + B, tr_);
             z1c = zc;
@@ -612,9 +757,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             env.fence();
         }
         // trans_0 = log N(z_0; m0, P0)
-        const V rr = z1r - m0r;
-        const V ur = qsum(P0i * (z1c - m0c));
-        const V tr0 = (c_lat - half * csum(rr * ur)) - hl0;
+        const V tr0 = gauss(z1r - m0r, z1c - m0c, P0i, hl0);
         s_trans += tr0;
         if (t_trans) env.put_scalar(t_trans + b, tr0);
     }
@@ -623,7 +766,7 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
     sums[2] += s_post;
     env.fence();
 
-    if constexpr (GRAD) {
+    if constexpr (GRAD && KR_STOP_AFTER > 2) {
         const R gs0 = g.g_scale ? g.g_scale[0] : R(1);
         const R gs1 = g.g_scale ? g.g_scale[g.g_scale_stride] : R(1);
         const R gs2 = g.g_scale ? g.g_scale[2 * g.g_scale_stride] : R(1);
@@ -632,18 +775,23 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
 
         // ---- phase SA: adjoint of the terms and of the RTS steps, t = 0..T-1 -----------------
         {
-            V zc = env.ld_vec_c(0, SL::V_Z), zr = env.ld_vec_r(0, SL::V_Z);
+            V zc = env.ld_vec_c(env.at_vec(0, SL::V_Z)), zr = env.ld_vec_r(env.at_vec(0, SL::V_Z));
             // trans_0: u = P0^-1 (z_0 - m0)
             V utr = qsum(P0i * (zc - m0c)), utc = csum(P0i * (zr - m0r));
             acc.m0c += wt * utc;
             acc.P0 += (wt * half) * (utr * utc - P0i);
-            V suuQ = zero, suuR = zero;
+            V suuQ = zero, suuR[P][P];
+            KV_UNROLL
+            for (int r = 0; r < P; ++r) {
+                KV_UNROLL
+                for (int c = 0; c < P; ++c) suuR[r][c] = zero;
+            }
             V msbc = zero, msbr = zero, Psb = zero;
             V dA_row[K];
             KV_UNROLL
             for (int k = 0; k < K; ++k) dA_row[k] = zero;
             struct In {
-                V wn[K], ec, er, ar, ac;
+                V wn[K], ec, er, a[P];
             };
             auto load_in = [&](int t) {
                 In x;
@@ -651,38 +799,48 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 weights(tb + B, x.wn);
                 x.ec = env.template vec_c<N>(f.eps + tb * N);
                 x.er = env.template vec_r<N>(f.eps + tb * N);
-                x.ar = env.template vec_r<P>(f.a + tb * P);
-                x.ac = env.template vec_c<P>(f.a + tb * P);
+                observation(tb, x.a);
                 return x;
             };
             V w[K];
             weights(b, w);
             In in = load_in(0);
-            for (int t = 0; t < T; ++t) {
+            // The adjoint of the terms of step t (obs_t, trans_{t+1} unless LAST, post_t, the
+            // sample z_t): adds to msb / Psb, writes d_a[t] and d_alpha[t], leaves A_{t+1}'s
+            // gradient from trans_{t+1} in AbT and u of trans_{t+1} in unr / unc.
+            auto terms_adjoint = [&](int t, auto last_c, V& AbT, V& z1c, V& z1r, V& unr, V& unc) {
+                constexpr bool LAST = decltype(last_c)::value;
                 const long tb = (long)t * B + b;
-                const bool last = t == T - 1;
-                const In nxt = load_in(clamp_t(t + 1));
-                const V* wn = in.wn;
-                const V C = mix_row<V, K>(w, CK), CT = mix_row<V, K>(w, CKT);
-                const V An = mix_row<V, K>(wn, AK), AnT = mix_row<V, K>(wn, AKT);
-                const V L = env.template ld_mat<L_NAT>(t, SL::M_L);
-                const V LT = env.template ld_mat<L_TRN>(t, SL::M_L);
-                const V ec = in.ec, er = in.er;
+                [[maybe_unused]] const V* wn = in.wn;
+                V cc[P], cr[P];
+                mix_rows<V, P, K>(w, CKc, cc);
+                mix_rows<V, P, K>(w, CKr, cr);
+                const auto locL = env.at_mat(t, SL::M_L);
+                const V L = env.ld_mat(locL), LT = env.ld_mat_t(locL);
                 // obs_t = log N(a_t; C_t z_t, R):  u = R^-1 (a - C z)
-                const V rr = in.ar - qsum(C * zc);
-                const V rc = in.ac - csum(CT * zr);
-                const V ur = qsum(Ri * rc), uc = csum(Ri * rr);
-                env.template put_vec_c<P>(g.d_a + tb * P, (-wo) * uc);
-                V Cb = wo * (ur * zc);
-                V zbc = wo * csum(C * ur) - wt * utc;
-                V zbr = wo * qsum(CT * uc) - wt * utr;
-                suuR += ur * uc;
-                V AbT = zero;   // gradient w.r.t. A_{t+1}, transposed
-                V z1c = zero, z1r = zero, unr = zero, unc = zero;
-                if (!last) {
+                V res[P], u[P], cb[P];
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) res[r] = in.a[r] - qsum(cc[r] * zc);
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) {
+                    u[r] = dotp(Ri[r], res);
+                    env.put_scalar(g.d_a + tb * P + r, (-wo) * u[r]);
+                    cb[r] = (wo * u[r]) * zc;                    // row r of the gradient w.r.t. C_t
+                }
+                V zbc = (-wt) * utc, zbr = (-wt) * utr;
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) {
+                    zbc = zbc + (wo * u[r]) * cc[r];             // C^T u
+                    zbr = zbr + (wo * u[r]) * cr[r];
+                    KV_UNROLL
+                    for (int c = 0; c < P; ++c) suuR[r][c] = suuR[r][c] + u[r] * u[c];
+                }
+                AbT = zero;   // gradient w.r.t. A_{t+1}, transposed
+                if constexpr (!LAST) {
                     // trans_{t+1} = log N(z_{t+1}; A_{t+1} z_t, Q):  u = Q^-1 (z_{t+1} - A z_t)
-                    z1c = env.ld_vec_c(t + 1, SL::V_Z);
-                    z1r = env.ld_vec_r(t + 1, SL::V_Z);
+                    const V An = mix_row<V, K>(wn, AK), AnT = mix_row<V, K>(wn, AKT);
+                    z1c = env.ld_vec_c(env.at_vec(t + 1, SL::V_Z));
+                    z1r = env.ld_vec_r(env.at_vec(t + 1, SL::V_Z));
                     const V qr = z1r - qsum(An * zc), qc = z1c - csum(AnT * zr);
                     unr = qsum(Qi * qc);
                     unc = csum(Qi * qr);
@@ -696,51 +854,61 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 msbr += zbr;
                 {
                     const V gc = csum(L * zbr), gr = qsum(LT * zbc);       // L^T zb
-                    const V Psym = sel<M_LOWER>(gr * ec, gc * er) - sel<m_diag_lt(N)>(V(wp), zero);
-                    const V LiT = tri_inverse_t<N>(L);
-                    const V LiTs = skew(LiT);
-                    Psb += half * mm_s(LiTs, tr(mm_s(LiTs, Psym)));         // 1/2 Li^T Psym Li
+                    const V Psym =
+                        sel<M_LOWER>(gr * in.ec, gc * in.er) - sel<m_diag_lt(N)>(V(wp), zero);
+                    const V LiT = tri_inverse_t<N>(L, [&](auto kc) {
+                        return env.template ld_colc<decltype(kc)::value>(locL);
+                    });
+                    env.st_mat(env.scr(0), mm4(skew(LiT), rots(Psym)));   // V = LiT Psym
+                    Psb += half * mm4(LiT, env.ld_rows4(env.scr(0)));     // 1/2 LiT V^T
                 }
                 // C-part of d_alpha[t], basis gradient of C
                 KV_UNROLL
                 for (int k = 0; k < K; ++k) {
-                    env.put_scalar(g.d_alpha + tb * K + k, dA_row[k] + rsum(Cb * CK[k]));
-                    acc.CK[k] += w[k] * Cb;
+                    env.put_scalar(g.d_alpha + tb * K + k, dA_row[k] + qsum(dotp(cb, CKc[k])));
+                    KV_UNROLL
+                    for (int r = 0; r < P; ++r) acc.CKc[k][r] += w[k] * cb[r];
                 }
-                if (last) {
-                    env.st_vec(t, SL::V_BM, msbc);
-                    env.st_mat(t, SL::M_BP, Psb);
-                    env.st_vec(t, SL::V_BMN, zero);
-                    env.st_mat(t, SL::M_BPN, zero);
-                    break;
-                }
-                if ((unsigned)t < burn) {
-                    msbc = msbr = zero;
-                    Psb = zero;
-                }
-                // adjoint of the RTS step t
-                const V Pf = env.template ld_mat<L_NAT>(t, SL::M_PFILT);
-                const V dc = env.ld_vec_c(t, SL::V_D);
-                const V D = env.template ld_mat<L_NAT>(t, SL::M_D);
-                const V J = env.template ld_mat<L_NAT>(t, SL::M_J);
-                const V JT = env.template ld_mat<L_TRN>(t, SL::M_J);
-                const V Pi = env.template ld_mat<L_NAT>(t, SL::M_PINV);
-                const V Ans = mix_row<V, K>(wn, AKs), AnTs = mix_row<V, K>(wn, AKTs);
-                const V W = mm_s(AnTs, Pi);                    // An^T Pn^-1
+            };
+            for (int t = 0; t < T - 1; ++t) {
+                const In nxt = load_in(t + 1);
+                const V* wn = in.wn;
+                const V AnT = mix_row<V, K>(wn, AKT);
+                // what the RTS adjoint needs from the stored state and the inputs alone
+                const auto locJ = env.at_mat(t, SL::M_J);
+                const auto locPi = env.at_mat(t, SL::M_PINV);
+                env.st_mat(env.scr(4), AnT);                           // read back as rows: X An
+                const V Pf = env.ld_mat(env.at_mat(t, SL::M_PFILT));
+                const V dc = env.ld_vec_c(env.at_vec(t, SL::V_D));
+                const V J = env.ld_mat(locJ), JT = env.ld_mat_t(locJ);
+                const V Pi = env.ld_mat(locPi);
+                const Q4<V> Pi4 = env.ld_rows4(locPi);
+                env.st_mat_t(env.scr(1), mm4(J, env.ld_rows4(env.at_mat(t, SL::M_D))));   // J D
+                const V WTs = skew(mm4(Pi, env.ld_rows4(env.scr(4))));   // Pn^-1 An = W^T
+                const V JTs = skew(JT), Pfs = skew(Pf);
+                const Q4<V> Jc4 = env.ld_cols4(locJ);
+                V AbT, z1c, z1r, unr, unc;
+                terms_adjoint(t, std::false_type{}, AbT, z1c, z1r, unr, unc);
+                // steps below the burn-in pass no gradient on to the filter's moments
+                const R keep = (unsigned)t < burn ? R(0) : R(1);
+                msbc = keep * msbc;
+                msbr = keep * msbr;
+                Psb = keep * Psb;
+                // adjoint of the RTS step t:  J = Pf W, W = An^T Pn^-1, with Z = Jb Pn^-1
                 const V Hs = Psb + tr(Psb);
                 const V H = sym ? half * Hs : Psb;
-                const V Jb = msbr * dc + mm(Hs, mm(J, D));     // msb d^T + (H + H^T) J D
-                const V dbc = csum(J * msbr), dbr = qsum(JT * msbc);        // J^T msb
-                const V Db = mm(JT, mm(H, J));                  // J^T H J
-                const V Pfb = H + mm(Jb, tr(W));
-                const V Wb = mm(Pf, Jb);
-                AbT += mm(Wb, Pi);                              // (Pn^-1 Wb^T)^T
-                const V Pib = mm_s(Ans, Wb);
-                const V Pnb = -(mm(Pi, mm(Pib, Pi))) - Db;
-                env.st_vec(t, SL::V_BM, msbc);
-                env.st_mat(t, SL::M_BP, Pfb);
-                env.st_vec(t, SL::V_BMN, -dbc);
-                env.st_mat(t, SL::M_BPN, Pnb);
+                const V Jb = msbr * dc + mm4(Hs, env.ld_rows4(env.scr(1)));   // msb d^T + (H + H^T) J D
+                const V dbc = csum(J * msbr), dbr = qsum(JT * msbc);   // J^T msb
+                const V Db = mm4(JTs, rots(mm4(H, Jc4)));              // J^T (H J)
+                const V Z = mm4(Jb, Pi4);
+                const V Pfb = H + mm4(Z, env.ld_rows4(env.scr(4)));    // + Jb W^T = Z An
+                const V PZ = mm4(Pfs, rots(Z));                        // Pf Z = (Pn^-1 Wb^T)^T
+                AbT += PZ;
+                const V Pnb = -mm4(WTs, rots(PZ)) - Db;                // -Pn^-1 (An Pf Jb) Pn^-1 - Db
+                env.st_vec(env.at_vec(t, SL::V_BM), msbc);
+                env.st_mat(env.at_mat(t, SL::M_BP), Pfb);
+                env.st_vec(env.at_vec(t, SL::V_BMN), -dbc);
+                env.st_mat(env.at_mat(t, SL::M_BPN), Pnb);
                 // A-part of d_alpha[t+1], basis gradient of A (transposed layout)
                 KV_UNROLL
                 for (int k = 0; k < K; ++k) {
@@ -759,14 +927,28 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                 in = nxt;
                 env.fence();
             }
+            {
+                // the last step: smoothed == filtered there (no burn-in gate)
+                V AbT, z1c, z1r, unr, unc;
+                terms_adjoint(T - 1, std::true_type{}, AbT, z1c, z1r, unr, unc);
+                env.st_vec(env.at_vec(T - 1, SL::V_BM), msbc);
+                env.st_mat(env.at_mat(T - 1, SL::M_BP), Psb);
+                env.st_vec(env.at_vec(T - 1, SL::V_BMN), zero);
+                env.st_mat(env.at_mat(T - 1, SL::M_BPN), zero);
+            }
             // covariance gradients of the Gaussian terms: w/2 (sum u u^T - count Sigma^-1)
-            acc.Rm += (wo * half) * (suuR - R(T) * Ri);
+            KV_UNROLL
+            for (int r = 0; r < P; ++r) {
+                KV_UNROLL
+                for (int c = 0; c < P; ++c)
+                    acc.Rs[r][c] += (wo * half) * (suuR[r][c] - R(T) * Ri[r][c]);
+            }
             acc.Q += (wt * half) * (suuQ - R(T - 1) * Qi);
         }
         env.fence();
 
         // ---- phase FA: filter adjoint, t = T-1..0 ----------------------------------------------
-        {
+        if (KR_STOP_AFTER > 3) {
             V mpbc = zero, mpbr = zero, Ppb = zero;
             V dwn[K];
             KV_UNROLL
@@ -774,60 +956,66 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             // inputs of step t: weights of step t, observation, mask, and what phase SA left
             // in d_alpha[t+1] and d_a[t]
             struct In {
-                V w[K], ar, mu, da_old[K], a_old;
+                V w[K], a[P], mu, da_old[K], a_old[P];
             };
             auto load_in = [&](int t) {
                 In x;
                 const long tb = (long)t * B + b;
                 weights(tb, x.w);
-                x.ar = env.template vec_r<P>(f.a + tb * P);
+                observation(tb, x.a);
                 x.mu = f.mask ? env.scalar(f.mask + tb) : V(R(1));
                 KV_UNROLL
                 for (int k = 0; k < K; ++k)
                     x.da_old[k] = t + 1 < T ? env.scalar(g.d_alpha + (tb + B) * K + k) : zero;
-                x.a_old = env.template vec_c<P>(g.d_a + tb * P);
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) x.a_old[r] = env.scalar(g.d_a + tb * P + r);
                 return x;
             };
             V wn[K];
             weights((long)T * B + b, wn);
             In in = load_in(T - 1);
+            // the prediction step 0 starts from sits in two scratch slots, so that every step
+            // reads its prediction the same way
+            env.st_mat(env.scr(2), P0);
+            env.st_vec(env.scr(3), m0c);
+            env.fence();
             for (int t = T - 1; t >= 0; --t) {
                 const long tb = (long)t * B + b;
                 const In nxt = load_in(clamp_t(t - 1));
                 const V* w = in.w;
-                const V ar = in.ar;
-                const V C = mix_row<V, K>(w, CK), Cs = mix_row<V, K>(w, CKs),
-                        CT = mix_row<V, K>(w, CKT), CTs = mix_row<V, K>(w, CKTs);
-                const V An = mix_row<V, K>(wn, AK), Ans = mix_row<V, K>(wn, AKs),
-                        AnT = mix_row<V, K>(wn, AKT), AnTs = mix_row<V, K>(wn, AKTs);
-                V mpc, Pp;
-                if (t > 0) {
-                    mpc = env.ld_vec_c(t - 1, SL::V_MN);
-                    Pp = env.template ld_mat<L_NAT>(t - 1, SL::M_PNEXT);
-                } else {
-                    mpc = m0c;
-                    Pp = P0;
-                }
-                const V mc = env.ld_vec_c(t, SL::V_M);
-                const V Pf = env.template ld_mat<L_NAT>(t, SL::M_PFILT);
+                V cc[P], cr[P];
+                mix_rows<V, P, K>(w, CKc, cc);
+                mix_rows<V, P, K>(w, CKr, cr);
+                const V An = mix_row<V, K>(wn, AK), AnT = mix_row<V, K>(wn, AKT);
+                env.st_mat(env.scr(4), AnT);          // read back as rows: X An
+                const V mpc = env.ld_vec_c(t > 0 ? env.at_vec(t - 1, SL::V_MN) : env.scr(3));
+                const V Pp = env.ld_mat(t > 0 ? env.at_mat(t - 1, SL::M_PNEXT) : env.scr(2));
+                const V mc = env.ld_vec_c(env.at_vec(t, SL::V_M));
                 // 1. gradients of the step's four outputs
-                V mbc = env.ld_vec_c(t, SL::V_BM), mbr = env.ld_vec_r(t, SL::V_BM);
-                V Pb = env.template ld_mat<L_NAT>(t, SL::M_BP);
-                mpbc += env.ld_vec_c(t, SL::V_BMN);
-                mpbr += env.ld_vec_r(t, SL::V_BMN);
-                Ppb += env.template ld_mat<L_NAT>(t, SL::M_BPN);
-                if ((unsigned)t < burn) {
-                    mbc = mbr = mpbc = mpbr = zero;
-                    Pb = Ppb = zero;
+                V mbc = env.ld_vec_c(env.at_vec(t, SL::V_BM)), mbr = env.ld_vec_r(env.at_vec(t, SL::V_BM));
+                V Pb = env.ld_mat(env.at_mat(t, SL::M_BP));
+                mpbc += env.ld_vec_c(env.at_vec(t, SL::V_BMN));
+                mpbr += env.ld_vec_r(env.at_vec(t, SL::V_BMN));
+                Ppb += env.ld_mat(env.at_mat(t, SL::M_BPN));
+                {
+                    // steps below the burn-in pass no gradient on
+                    const R keep = (unsigned)t < burn ? R(0) : R(1);
+                    mbc = keep * mbc;
+                    mbr = keep * mbr;
+                    mpbc = keep * mpbc;
+                    mpbr = keep * mpbr;
+                    Pb = keep * Pb;
+                    Ppb = keep * Ppb;
                 }
                 // 2. time update  m' = An m,  P' = sym(An Pf An^T + Q)
                 {
                     const V Hs = Ppb + tr(Ppb);
                     const V H = sym ? half * Hs : Ppb;
-                    const V Ab = mpbr * mc + mm(Hs, mm_s(Ans, Pf));   // mpb m^T + (H + H^T) An Pf
+                    env.st_mat_t(env.scr(0), mm4(An, env.ld_rows4(env.at_mat(t, SL::M_PFILT))));   // An Pf
+                    const V Ab = mpbr * mc + mm4(Hs, env.ld_rows4(env.scr(0)));   // mpb m^T + (H + H^T) An Pf
                     mbc += csum(An * mpbr);                           // An^T mpb
                     mbr += qsum(AnT * mpbc);
-                    Pb += mm_s(AnTs, mm(H, An));                      // An^T H An
+                    Pb += mm4(mix_row<V, K>(wn, AKTs), rots(mm4(H, env.ld_rows4(env.scr(4)))));   // An^T (H An)
                     acc.Q += H;
                     // d_alpha[t+1] is complete here
                     KV_UNROLL
@@ -838,45 +1026,68 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
                     }
                 }
                 // 3. measurement update
-                const Update u = update_terms_row(C, Cs, CT, mpc, Pp, ar, 0);
+                const Update u = update_terms_row(cc, cr, mpc, Pp, in.a, 0);
                 const V H2s = Pb + tr(Pb);
                 const V H2 = sym ? half * H2s : Pb;
-                V mobc = mbc, mobr = mbr, Pob = H2;
-                if (f.mask) {
-                    mobc = in.mu * mbc;
-                    mobr = in.mu * mbr;
-                    Pob = in.mu * H2;
-                }
+                // (mask weight: 1 without a mask)
+                const V mobr = in.mu * mbr, Pob = in.mu * H2;
+                const V PobT = sym ? Pob : in.mu * (H2s - Pb);
                 mpbc = mbc;          // blend + identity term of m_obs
                 mpbr = mbr;
                 Ppb = H2;
-                const V GT = tr(u.G);
-                const V Gb = mobr * u.rc - mm(Pob, u.F);              // mob r^T - Pob M^T
-                const V rbc_ = csum(u.G * mobr), rbr = qsum(GT * mobc);   // G^T mob
-                env.template put_vec_c<P>(g.d_a + tb * P, in.a_old + rbc_);
-                V Cb = -(rbr * mpc);
-                mpbc -= csum(C * rbr);                                // C^T rb
-                mpbr -= qsum(CT * rbc_);
-                const V Mb = -mm(GT, Pob);                            // -G^T Pob
-                Cb += mm(Mb, Pp);
-                Ppb += mm_s(CTs, Mb);                                 // C^T Mb
-                const V Fb = mm(Gb, u.Si);
-                const V Sib = mm(u.M, Gb);                            // F^T Gb
-                const V Sb = -mm(u.Si, mm(Sib, u.Si));
-                Ppb += mm(Fb, C);
-                Cb += mm(tr(Fb), Pp);
-                Cb += mm(Sb + tr(Sb), u.M);                           // Sb C Pp^T + Sb^T C Pp
-                Ppb += mm_s(CTs, mm(Sb, C));                          // C^T Sb C
-                acc.Rm += Sb;
+                // m_obs = mp + sum_r g_r r_r,  P_obs = Pp - sum_r g_r (row r of M):
+                V gbr[P], rb[P], cb[P], mkc[P], mkr[P], fbr[P];
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) {
+                    gbr[r] = mobr * u.r[r] - qsum(Pob * u.fc[r]);      // gradient w.r.t. g_r
+                    rb[r] = csum(u.gr[r] * mobr);                      // g_r . mob
+                    env.put_scalar(g.d_a + tb * P + r, in.a_old[r] + rb[r]);
+                    cb[r] = -(rb[r] * mpc);
+                    mpbc = mpbc - rb[r] * cc[r];                       // C^T rb
+                    mpbr = mpbr - rb[r] * cr[r];
+                    mkc[r] = -csum(Pob * u.gr[r]);                     // gradient w.r.t. row r of M:
+                    mkr[r] = -qsum(PobT * u.gc[r]);                    // -Pob^T g_r, both forms
+                    cb[r] = cb[r] + csum(Pp * mkr[r]);                 // M = C Pp
+                    Ppb = Ppb + cr[r] * mkc[r];
+                }
+                // G = F Si:  Fb = Gb Si^T,  Sb = -Si^T (F^T Gb) Si^T = -G^T Fb
+                V Sb[P][P];
+                KV_UNROLL
+                for (int c = 0; c < P; ++c) {
+                    fbr[c] = gbr[0] * u.Si[c][0];
+                    KV_UNROLL
+                    for (int r = 1; r < P; ++r) fbr[c] = fbr[c] + gbr[r] * u.Si[c][r];
+                }
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) {
+                    KV_UNROLL
+                    for (int c = 0; c < P; ++c) Sb[r][c] = -csum(u.gr[r] * fbr[c]);
+                }
+                // F = Pp C^T;  S = C Pp C^T + R
+                KV_UNROLL
+                for (int r = 0; r < P; ++r) {
+                    Ppb = Ppb + fbr[r] * cc[r];
+                    cb[r] = cb[r] + csum(Pp * fbr[r]);
+                    V sc = Sb[r][0] * cc[0];
+                    KV_UNROLL
+                    for (int c = 0; c < P; ++c) {
+                        cb[r] = cb[r] + (Sb[r][c] + Sb[c][r]) * u.fc[c];   // Sb C Pp^T + Sb^T C Pp
+                        if (c > 0) sc = sc + Sb[r][c] * cc[c];
+                        acc.Rs[r][c] += Sb[r][c];
+                    }
+                    Ppb = Ppb + cr[r] * sc;                                // C^T Sb C
+                }
                 // 4. C-part of d_alpha[t]
                 KV_UNROLL
                 for (int k = 0; k < K; ++k) {
-                    dwn[k] = rsum(Cb * CK[k]);
-                    acc.CK[k] += w[k] * Cb;
+                    dwn[k] = qsum(dotp(cb, CKc[k]));
+                    KV_UNROLL
+                    for (int r = 0; r < P; ++r) acc.CKc[k][r] += w[k] * cb[r];
                 }
                 KV_UNROLL
                 for (int k = 0; k < K; ++k) wn[k] = w[k];
                 in = nxt;
+                env.fence();
             }
             // d_alpha[0]: C-part of step 0 added to what phase SA wrote
             KV_UNROLL

@@ -24,8 +24,9 @@ constexpr int ROW_LDS_LIMIT = 65536;  // bytes of LDS one workgroup may use here
 template <bool GRAD>
 struct DevRowEnv {
     using SL = row::Slots<GRAD>;
+    using Loc = float*;
     float* lds;
-    int l16, li, lj, sq;
+    int T, l16, li, lj, sq;
     bool active;
 
     __device__ __forceinline__ float scalar(const float* p) const { return *p; }
@@ -50,29 +51,39 @@ struct DevRowEnv {
     __device__ __forceinline__ void put_scalar(float* p, float x) const {
         if (active && l16 == 0) *p = x;
     }
-    template <int LEN>
-    __device__ __forceinline__ void put_vec_c(float* p, float xc) const {
-        if (active && li == 0 && lj < LEN) p[lj] = xc;
+    // a step is STEP floats per sequence: the wavefront's four sequences side by side per slot
+    __device__ __forceinline__ Loc at_mat(int t, int slot) const {
+        return lds + (long)t * (SL::STEP * ROW_SEQS) + slot * ROW_SEQS + sq * 16;
     }
-    __device__ __forceinline__ float* step(int t) const { return lds + (long)t * (SL::STEP * ROW_SEQS); }
-    __device__ __forceinline__ void st_mat(int t, int slot, float x) const {
-        step(t)[slot * ROW_SEQS + sq * 16 + l16] = x;
+    __device__ __forceinline__ Loc at_vec(int t, int slot) const {
+        return lds + (long)t * (SL::STEP * ROW_SEQS) + slot * ROW_SEQS + sq * 4;
     }
-    template <int LAY>
-    __device__ __forceinline__ float ld_mat(int t, int slot) const {
-        const int off = LAY == row::L_NAT ? l16 : 4 * lj + li;
-        static_assert(LAY == row::L_NAT || LAY == row::L_TRN, "stored matrices are read plain or transposed");
-        return step(t)[slot * ROW_SEQS + sq * 16 + off];
+    __device__ __forceinline__ Loc scr(int i) const {
+        return lds + (long)T * (SL::STEP * ROW_SEQS) + i * (16 * ROW_SEQS) + sq * 16;
     }
-    __device__ __forceinline__ void st_vec(int t, int slot, float xc) const {
-        if (li == 0) step(t)[slot * ROW_SEQS + sq * 4 + lj] = xc;
+    __device__ __forceinline__ void st_mat(Loc q, float x) const { q[l16] = x; }
+    __device__ __forceinline__ void st_mat_t(Loc q, float x) const { q[4 * lj + li] = x; }
+    __device__ __forceinline__ float ld_mat(Loc q) const { return q[l16]; }
+    __device__ __forceinline__ float ld_mat_t(Loc q) const { return q[4 * lj + li]; }
+    __device__ __forceinline__ row::Q4<float> ld_rows4(Loc q) const {
+        const float4 v = *reinterpret_cast<const float4*>(q + 4 * lj);
+        row::Q4<float> y;
+        y.v[0] = v.x; y.v[1] = v.y; y.v[2] = v.z; y.v[3] = v.w;
+        return y;
     }
-    __device__ __forceinline__ float ld_vec_c(int t, int slot) const {
-        return step(t)[slot * ROW_SEQS + sq * 4 + lj];
+    __device__ __forceinline__ row::Q4<float> ld_cols4(Loc q) const {
+        row::Q4<float> y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y.v[k] = q[4 * k + lj];
+        return y;
     }
-    __device__ __forceinline__ float ld_vec_r(int t, int slot) const {
-        return step(t)[slot * ROW_SEQS + sq * 4 + li];
+    template <int KK>
+    __device__ __forceinline__ float ld_colc(Loc q) const { return q[4 * lj + KK]; }
+    __device__ __forceinline__ void st_vec(Loc q, float xc) const {
+        if (li == 0) q[lj] = xc;
     }
+    __device__ __forceinline__ float ld_vec_c(Loc q) const { return q[lj]; }
+    __device__ __forceinline__ float ld_vec_r(Loc q) const { return q[li]; }
     // orders this wavefront's LDS accesses: a slot written by one lane is read by another
     __device__ __forceinline__ void fence() const {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -89,14 +100,15 @@ __device__ __forceinline__ float sum_over_sequences(float x) {
 }
 
 // sums_partial: (rows, 3) or null; grad_partial: (rows, LossParamGrads::LEN), GRAD only
-template <int N, int P, int K, bool GRAD>
+template <int N, int P, int K, bool GRAD, bool SYM>
 __global__ void __launch_bounds__(64) loss_row_kernel(LossBwdArgs<float> g, float* sums_partial,
                                                       float* grad_partial) {
-    extern __shared__ float row_lds[];
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
     using PG = LossParamGrads<N, P, K>;
     const int lane = threadIdx.x;
     DevRowEnv<GRAD> env;
     env.lds = row_lds;
+    env.T = g.f.T;
     env.l16 = lane & 15;
     env.li = env.l16 >> 2;
     env.lj = env.l16 & 3;
@@ -106,10 +118,10 @@ __global__ void __launch_bounds__(64) loss_row_kernel(LossBwdArgs<float> g, floa
     if (!env.active) b = g.f.B - 1;   // stays in step with the wavefront, writes nothing
 
     float sums[3] = {0.f, 0.f, 0.f};
-    row::RowAcc<float, K> acc;
+    row::RowAcc<float, P, K> acc;
     row::zero_acc(acc);
     int st = 0;
-    row::loss_row_sequence<float, float, N, P, K, GRAD>(env, g, b, sums, acc, st);
+    row::loss_row_sequence<float, float, N, P, K, GRAD, SYM>(env, g, b, sums, acc, st);
     if (st && env.active && g.f.status) atomicOr(g.f.status, st);
 
     if (sums_partial) {
@@ -128,13 +140,22 @@ __global__ void __launch_bounds__(64) loss_row_kernel(LossBwdArgs<float> g, floa
         for (int k = 0; k < K; ++k) {
             const float a = sum_over_sequences(on * (acc.AK[k] + row::tr(acc.AKT[k])));
             if (first && i < N && j < N) out[PG::OFF_A + k * N * N + i * N + j] = a;
-            const float c = sum_over_sequences(on * acc.CK[k]);
-            if (first && i < P && j < N) out[PG::OFF_C + k * P * N + i * N + j] = c;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const float c = sum_over_sequences(on * acc.CKc[k][r]);
+                if (first && i == 0 && j < N) out[PG::OFF_C + (k * P + r) * N + j] = c;
+            }
         }
         const float q = sum_over_sequences(on * acc.Q);
         if (first && i < N && j < N) out[PG::OFF_Q + i * N + j] = q;
-        const float r = sum_over_sequences(on * acc.Rm);
-        if (first && i < P && j < P) out[PG::OFF_R + i * P + j] = r;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const float v = sum_over_sequences(on * acc.Rs[r][c]);
+                if (lane == 0) out[PG::OFF_R + r * P + c] = v;
+            }
+        }
         const float m0 = sum_over_sequences(on * acc.m0c);
         if (first && i == 0 && j < N) out[PG::OFF_M0 + j] = m0;
         const float p0 = sum_over_sequences(on * acc.P0);
@@ -142,20 +163,43 @@ __global__ void __launch_bounds__(64) loss_row_kernel(LossBwdArgs<float> g, floa
     }
 }
 
-// out (4) = [ w0 * sum_r partial[r][0], w1 * ..., w2 * ..., their total ], fixed order.
-__global__ void __launch_bounds__(256) loss_row_finish_kernel(const float* partial, long rows,
-                                                             float w0, float w1, float w2,
-                                                             float* out) {
+// The sums over the wavefronts' rows, in a fixed order, as ONE launch after the main kernel:
+// workgroup c < len adds column c of the (rows, len) parameter-gradient partials and routes it
+// to its output tensor; workgroup len (present when sums != null) adds the three term columns
+// and writes out (4) = [ w0 * sum obs, w1 * sum trans, w2 * sum post, their total ].
+__global__ void __launch_bounds__(256) loss_row_sums_kernel(const float* grads, const float* sums,
+                                                           long rows, int len, ReduceSegments seg,
+                                                           float w0, float w1, float w2,
+                                                           float* out) {
     __shared__ float sm[3][256 / WAVE];
+    const int c = blockIdx.x;
+    const int wave = threadIdx.x / WAVE;
+    const bool lead = (threadIdx.x & (WAVE - 1)) == 0;
+    if (c < len) {
+        float s = 0.f;
+        for (long r = threadIdx.x; r < rows; r += 256) s += grads[r * len + c];
+        s = wave_sum<float>(s);
+        if (lead) sm[0][wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < 256 / WAVE; ++w) tot += sm[0][w];
+            for (int i = 0; i < seg.count; ++i) {
+                if (c >= seg.begin[i] && c < seg.begin[i + 1] && seg.out[i])
+                    static_cast<float*>(seg.out[i])[c - seg.begin[i]] = tot;
+            }
+        }
+        return;
+    }
     float s[3] = {0.f, 0.f, 0.f};
     for (long r = threadIdx.x; r < rows; r += 256) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) s[e] += partial[r * 3 + e];
+        for (int e = 0; e < 3; ++e) s[e] += sums[r * 3 + e];
     }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         const float v = wave_sum<float>(s[e]);
-        if ((threadIdx.x & (WAVE - 1)) == 0) sm[e][threadIdx.x / WAVE] = v;
+        if (lead) sm[e][wave] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -174,7 +218,7 @@ __global__ void __launch_bounds__(256) loss_row_finish_kernel(const float* parti
 
 template <bool GRAD>
 size_t row_lds_bytes(int T) {
-    return (size_t)T * row::Slots<GRAD>::STEP * ROW_SEQS * sizeof(float);
+    return ((size_t)T * row::Slots<GRAD>::STEP + row::SCRATCH * 16) * ROW_SEQS * sizeof(float);
 }
 
 LossBwdArgs<float> make_row_args(const kvae_dims* d, const kvae_loss_fwd* io) {
@@ -207,10 +251,16 @@ int row_forward(const kvae_dims* d, const kvae_loss_fwd* io, void* ws, size_t ws
     const long rows = row_loss_rows(d->B);
     if (ws_bytes < (size_t)rows * 3 * sizeof(float)) return KVAE_E_WORKSPACE;
     LossBwdArgs<float> g = make_row_args(d, io);
-    hipLaunchKernelGGL((loss_row_kernel<N, P, K, false>), dim3(rows), dim3(64),
-                       row_lds_bytes<false>(d->T), s, g, (float*)ws, (float*)nullptr);
-    hipLaunchKernelGGL(loss_row_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, rows,
-                       (float)io->w_obs, (float)io->w_trans, (float)io->w_post, (float*)io->out);
+    if (d->symmetrize)
+        hipLaunchKernelGGL((loss_row_kernel<N, P, K, false, true>), dim3(rows), dim3(64),
+                           row_lds_bytes<false>(d->T), s, g, (float*)ws, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((loss_row_kernel<N, P, K, false, false>), dim3(rows), dim3(64),
+                           row_lds_bytes<false>(d->T), s, g, (float*)ws, (float*)nullptr);
+    ReduceSegments none = {};
+    hipLaunchKernelGGL(loss_row_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)nullptr,
+                       (const float*)ws, rows, 0, none, (float)io->w_obs, (float)io->w_trans,
+                       (float)io->w_post, (float*)io->out);
     return launch_status();
 }
 
@@ -232,21 +282,30 @@ int row_backward(const kvae_dims* d, const kvae_loss_bwd* io, void* ws, size_t w
     g.d_alpha = (float*)io->d_alpha;
     float* grad_partial = (float*)ws;
     float* sums_partial = with_value ? grad_partial + rows * PG::LEN : nullptr;
-    hipLaunchKernelGGL((loss_row_kernel<N, P, K, true>), dim3(rows), dim3(64),
-                       row_lds_bytes<true>(d->T), s, g, sums_partial, grad_partial);
-    if (with_value)
-        hipLaunchKernelGGL(loss_row_finish_kernel, dim3(1), dim3(256), 0, s,
-                           (const float*)sums_partial, rows, (float)fio.w_obs, (float)fio.w_trans,
-                           (float)fio.w_post, (float*)fio.out);
+    if (d->symmetrize)
+        hipLaunchKernelGGL((loss_row_kernel<N, P, K, true, true>), dim3(rows), dim3(64),
+                           row_lds_bytes<true>(d->T), s, g, sums_partial, grad_partial);
+    else
+        hipLaunchKernelGGL((loss_row_kernel<N, P, K, true, false>), dim3(rows), dim3(64),
+                           row_lds_bytes<true>(d->T), s, g, sums_partial, grad_partial);
     void* outs[6] = {io->d_A_K, io->d_C_K, io->d_Q, io->d_R, io->d_m0, io->d_P0};
     const int begin[7] = {PG::OFF_A, PG::OFF_C, PG::OFF_Q, PG::OFF_R, PG::OFF_M0, PG::OFF_P0, PG::LEN};
-    launch_reduce<float>(grad_partial, rows, PG::LEN, 6, outs, begin, s);
+    ReduceSegments seg;
+    seg.count = 6;
+    for (int i = 0; i < 6; ++i) seg.out[i] = outs[i];
+    for (int i = 0; i < 7; ++i) seg.begin[i] = begin[i];
+    hipLaunchKernelGGL(loss_row_sums_kernel, dim3(PG::LEN + (with_value ? 1 : 0)), dim3(256), 0, s,
+                       (const float*)grad_partial, (const float*)sums_partial, rows, (int)PG::LEN,
+                       seg, (float)fio.w_obs, (float)fio.w_trans, (float)fio.w_post,
+                       (float*)fio.out);
     return launch_status();
 }
 
 }  // namespace
 
+#ifndef KVAE_ROW_DIM_LIST   // (an experiment build may define a shorter list)
 #define KVAE_ROW_DIM_LIST(X) X(4, 2, 3) X(2, 1, 2) X(3, 2, 2) X(4, 2, 8)
+#endif
 
 long row_loss_rows(long B) { return (B + ROW_SEQS - 1) / ROW_SEQS; }
 

@@ -381,8 +381,10 @@ template <typename R, bool GRAD>
 struct HostRowEnv {
     using V = row::Row<R>;
     using SL = row::Slots<GRAD>;
+    using Loc = R*;
+    int T;
     std::vector<R> lds;
-    explicit HostRowEnv(int T) : lds((size_t)T * SL::STEP, R(0)) {}
+    explicit HostRowEnv(int T_) : T(T_), lds((size_t)T_ * SL::STEP + row::SCRATCH * 16, R(0)) {}
     V scalar(const R* p) const { return V(*p); }
     void fence() const {}
     template <int LEN>
@@ -407,38 +409,60 @@ struct HostRowEnv {
         return x;
     }
     void put_scalar(R* p, const V& x) const { *p = x.v[0]; }
-    template <int LEN>
-    void put_vec_c(R* p, const V& xc) const {
-        for (int j = 0; j < LEN; ++j) p[j] = xc.v[j];
+    Loc at_mat(int t, int slot) { return lds.data() + (size_t)t * SL::STEP + slot; }
+    Loc at_vec(int t, int slot) { return lds.data() + (size_t)t * SL::STEP + slot; }
+    Loc scr(int i) { return lds.data() + (size_t)T * SL::STEP + 16 * i; }
+    void st_mat(Loc q, const V& x) const {
+        for (int l = 0; l < 16; ++l) q[l] = x.v[l];
     }
-    void st_mat(int t, int slot, const V& x) {
-        for (int l = 0; l < 16; ++l) lds[(size_t)t * SL::STEP + slot + l] = x.v[l];
+    void st_mat_t(Loc q, const V& x) const {
+        for (int l = 0; l < 16; ++l) q[4 * (l & 3) + (l >> 2)] = x.v[l];
     }
-    template <int LAY>
-    V ld_mat(int t, int slot) const {
+    V ld_mat(Loc q) const {
         V x;
-        for (int l = 0; l < 16; ++l)
-            x.v[l] = lds[(size_t)t * SL::STEP + slot + 4 * row::lay_r(LAY, l >> 2, l & 3) +
-                         row::lay_c(LAY, l >> 2, l & 3)];
+        for (int l = 0; l < 16; ++l) x.v[l] = q[l];
         return x;
     }
-    void st_vec(int t, int slot, const V& xc) {
-        for (int j = 0; j < 4; ++j) lds[(size_t)t * SL::STEP + slot + j] = xc.v[j];
-    }
-    V ld_vec_c(int t, int slot) const {
+    V ld_mat_t(Loc q) const {
         V x;
-        for (int l = 0; l < 16; ++l) x.v[l] = lds[(size_t)t * SL::STEP + slot + (l & 3)];
+        for (int l = 0; l < 16; ++l) x.v[l] = q[4 * (l & 3) + (l >> 2)];
         return x;
     }
-    V ld_vec_r(int t, int slot) const {
+    row::Q4<V> ld_rows4(Loc q) const {
+        row::Q4<V> y;
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 16; ++l) y.v[k].v[l] = q[4 * (l & 3) + k];
+        return y;
+    }
+    row::Q4<V> ld_cols4(Loc q) const {
+        row::Q4<V> y;
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 16; ++l) y.v[k].v[l] = q[4 * k + (l & 3)];
+        return y;
+    }
+    template <int KK>
+    V ld_colc(Loc q) const {
         V x;
-        for (int l = 0; l < 16; ++l) x.v[l] = lds[(size_t)t * SL::STEP + slot + (l >> 2)];
+        for (int l = 0; l < 16; ++l) x.v[l] = q[4 * (l & 3) + KK];
+        return x;
+    }
+    void st_vec(Loc q, const V& xc) const {
+        for (int j = 0; j < 4; ++j) q[j] = xc.v[j];
+    }
+    V ld_vec_c(Loc q) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = q[l & 3];
+        return x;
+    }
+    V ld_vec_r(Loc q) const {
+        V x;
+        for (int l = 0; l < 16; ++l) x.v[l] = q[l >> 2];
         return x;
     }
 };
 
-template <typename R, int N, int P, int K, bool GRAD>
-int row_loss(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* bio) {
+template <typename R, int N, int P, int K, bool GRAD, bool SYM>
+int row_loss_sym(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* bio) {
     using V = row::Row<R>;
     LossBwdArgs<R> g;
     g.f = mkl<R>(d, fio);
@@ -449,12 +473,12 @@ int row_loss(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* 
     g.d_a = bio ? (R*)bio->d_a : nullptr; g.d_alpha = bio ? (R*)bio->d_alpha : nullptr;
     g.partial = nullptr;
     V sums[3] = {V(R(0)), V(R(0)), V(R(0))};
-    row::RowAcc<V, K> acc;
+    row::RowAcc<V, P, K> acc;
     row::zero_acc(acc);
     int st = 0;
     for (int b = 0; b < d->B; ++b) {
         HostRowEnv<R, GRAD> env(d->T);
-        row::loss_row_sequence<V, R, N, P, K, GRAD>(env, g, (long)b, sums, acc, st);
+        row::loss_row_sequence<V, R, N, P, K, GRAD, SYM>(env, g, (long)b, sums, acc, st);
     }
     if (st && fio->status) *fio->status |= st;
     if (fio->out) {
@@ -474,15 +498,25 @@ int row_loss(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* 
         };
         for (int k = 0; k < K; ++k) {
             mat_out(bio->d_A_K ? (R*)bio->d_A_K + k * N * N : nullptr, acc.AK[k], &acc.AKT[k], N, N);
-            mat_out(bio->d_C_K ? (R*)bio->d_C_K + k * P * N : nullptr, acc.CK[k], nullptr, P, N);
+            if (bio->d_C_K)
+                for (int r = 0; r < P; ++r)
+                    for (int j = 0; j < N; ++j)
+                        ((R*)bio->d_C_K)[(k * P + r) * N + j] = acc.CKc[k][r].v[j];
         }
         mat_out(bio->d_Q, acc.Q, nullptr, N, N);
-        mat_out(bio->d_R, acc.Rm, nullptr, P, P);
+        if (bio->d_R)
+            for (int r = 0; r < P; ++r)
+                for (int c = 0; c < P; ++c) ((R*)bio->d_R)[r * P + c] = acc.Rs[r][c].v[0];
         mat_out(bio->d_P0, acc.P0, nullptr, N, N);
         if (bio->d_m0)
             for (int j = 0; j < N; ++j) ((R*)bio->d_m0)[j] = acc.m0c.v[j];
     }
     return 0;
+}
+template <typename R, int N, int P, int K, bool GRAD>
+int row_loss(const kvae_dims* d, const kvae_loss_fwd* fio, const kvae_loss_bwd* bio) {
+    return d->symmetrize ? row_loss_sym<R, N, P, K, GRAD, true>(d, fio, bio)
+                         : row_loss_sym<R, N, P, K, GRAD, false>(d, fio, bio);
 }
 template <typename R, int N, int P, int K>
 int row_loss_fwd(const kvae_dims* d, const kvae_loss_fwd* io) {
