@@ -264,27 +264,37 @@ def time_fused_kernels(ssm, a, burn_in, iters=30):
               d_C_K=d["C_K"], d_Q=d["Q"], d_R=d["R"], d_m0=None, d_P0=None)
     nf = lib.kvae_workspace_bytes(C.byref(dims), capi.OP_LOSS_FWD)
     nb = lib.kvae_workspace_bytes(C.byref(dims), capi.OP_LOSS_BWD)
-    ws = torch.empty(max(nf, nb, 8), dtype=torch.uint8, device=dev)
+    nv = lib.kvae_workspace_bytes(C.byref(dims), capi.OP_LOSS_VALUE_AND_GRAD)
+    ws = torch.empty(max(nf, nb, nv, 8), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     tf = _timed(lambda: capi.check(lib.kvae_kalman_loss_forward(
         C.byref(dims), C.byref(lf), ws.data_ptr(), nf, stream)), iters)
     tb = _timed(lambda: capi.check(lib.kvae_kalman_loss_backward(
         C.byref(dims), C.byref(lb), ws.data_ptr(), nb, stream)), iters)
-    return {"loss_forward": tf, "loss_backward": tb}
+    # what the training step calls: value and gradient from one call
+    tv = _timed(lambda: capi.check(lib.kvae_kalman_loss_value_and_grad(
+        C.byref(dims), C.byref(lb), ws.data_ptr(), nv, stream)), iters)
+    on_chip = lib.kvae_loss_saved_bytes(C.byref(dims)) <= 256   # the 16-lanes-per-sequence form
+    return {"loss_value_and_grad": tv, "loss_forward": tf, "loss_backward": tb}, on_chip
 
 
-def fused_bytes(n, p, K, el):
-    """Compulsory global-memory bytes per sequence-step of the fused objective's two
-    launches: inputs (a, alpha, eps) read, the state handed from the forward to the
-    backward pass (filtered, predicted and smoothed means and covariances) written once
-    and read once, the gradients handed from the backward pass's first sweep to its second
-    written and read, d_a and d_alpha written."""
+def fused_bytes(n, p, K, el, on_chip=False):
+    """Compulsory global-memory bytes per sequence-step of the fused objective's calls.
+    With the per-step state on chip (16 lanes per sequence, LDS): the inputs (a, alpha, eps)
+    read and d_a, d_alpha written, nothing else.  Otherwise also the state handed from the
+    forward to the backward pass (filtered, predicted and smoothed means and covariances)
+    written once and read once and the gradients handed from the backward pass's first sweep
+    to its second written and read."""
     v, c = n, n * n
     inputs = p + K + n
+    if on_chip:
+        return {"loss_forward": el * inputs, "loss_backward": el * (inputs + p + K),
+                "loss_value_and_grad": el * (inputs + p + K)}
     saved = 3 * v + 3 * c
     bars = 2 * v + 2 * c
-    return {"loss_forward": el * (inputs + saved + (2 * v + 2 * c)),   # + the filter state re-read
-            "loss_backward": el * (inputs + saved + (2 * v + 2 * c) + 2 * bars + 2 * (p + K))}
+    fwd = el * (inputs + saved + (2 * v + 2 * c))                      # + the filter state re-read
+    bwd = el * (inputs + saved + (2 * v + 2 * c) + 2 * bars + 2 * (p + K))
+    return {"loss_forward": fwd, "loss_backward": bwd, "loss_value_and_grad": fwd + bwd}
 
 
 def time_kernels(ssm, a, burn_in, iters=30, synthetic_alpha=False):
@@ -759,9 +769,9 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, v)
     if args.net is None:
-        # c3's default is the network the one-launch masked filter holds in LDS; every other
-        # configuration uses the reference's default network
-        args.net = "mlp" if args.config == "c3" else "lstm"
+        # the reference's default network everywhere (--net mlp: the two-layer perceptron that
+        # the one-launch masked filter of c3 evaluates inside the kernel)
+        args.net = "lstm"
     defaults = {"c1": (50, 10), "c2": (50, 10), "c3": (5, 2), "c4": (3, 1), "c5": (10, 3)}
     if args.steps is None:
         args.steps = defaults[args.config][0]
@@ -845,13 +855,45 @@ def run_training(args, rank, world, dev, rehearsal):
         + ("synthetic mixing weights, six separate HIP kernels only, " if args.kernels_only
            else f"{args.net} weight network, ")
         + "filter+RTS smoother+ELBO terms fwd+bwd"
-        + (" (fused objective: one launch per direction)" if fused and not args.kernels_only
+        + (" (fused objective: value and gradient in one call)" if fused and not args.kernels_only
            else " (six separate kernels)"),
         {"seq_len": T, "batch_per_gpu": B, "global_batch": B * world, "burn_in": args.burn_in,
          "parallelism": f"dp{world}" + (" (rehearsal: one GPU, gloo)" if rehearsal else ""),
          "hip_graph": graphed is not None, "fused_objective": bool(fused)})
     if graph_note:
         result["config"]["hip_graph_note"] = graph_note
+    if args.net == "lstm" and not args.kernels_only:
+        # the Kalman path is fp32 throughout; the weight network's matrix products (78 % of the
+        # step) are not: say so, and time the same step with exact fp32 products beside it
+        from kalman_vae_amd import _capi as capi
+        lib = capi.load()
+        split = lib.kvae_lstm128_get_precision() == 1
+        result["config"]["weight_network_products"] = (
+            "bf16x3-split (fp32 operands as hi+lo bf16, three bf16 matrix instructions per "
+            "product, fp32 accumulation; about 1e-5 relative per product)" if split
+            else "fp32 matrix instructions")
+        result["config"]["kalman_path_arithmetic"] = "fp32"
+        if split:
+            result["config"]["workload"] += "; weight network products bf16x3-split"
+        if split and world == 1 and T <= 100:
+            _progress("timing the same step with exact fp32 weight-network products")
+            lib.kvae_lstm128_set_precision(0)
+            try:
+                exact = None
+                if graphed is not None:
+                    from kalman_vae_amd.graphed import GraphedElboStep
+                    g32 = GraphedElboStep(ssm, a, sc, burn_in=args.burn_in)
+                    exact = lambda: g32(None)
+                else:
+                    exact = eager_step
+                e32 = _timed_steps(exact, args, world, dev, rehearsal)
+                result["fp32_network"] = {
+                    "ms_per_step": e32 / args.steps * 1e3, "value": units * args.steps / e32,
+                    "unit": "sequence-steps/s",
+                    "note": "same step, same process, kvae_lstm128_set_precision(0): every "
+                            "product of the weight network on fp32 matrix instructions"}
+            finally:
+                lib.kvae_lstm128_set_precision(1)
     step_s = elapsed / args.steps
     fl = flops_forward(n, p, K)
     step_flops = 3 * sum(fl.values()) * units
@@ -862,17 +904,24 @@ def run_training(args, rank, world, dev, rehearsal):
         kernels = {}
         kal = None      # (name, seconds, flops, bytes) of the Kalman path's longest kernel
         if fused and not args.kernels_only:
-            ft = time_fused_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
-            fb = fused_bytes(n, p, K, 4)
-            ffl = {"loss_forward": sum(fl.values()), "loss_backward": 2 * sum(fl.values())}
+            ft, on_chip = time_fused_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
+            fb = fused_bytes(n, p, K, 4, on_chip)
+            ffl = {"loss_forward": sum(fl.values()), "loss_backward": 2 * sum(fl.values()),
+                   "loss_value_and_grad": 3 * sum(fl.values())}
             for name, sec in ft.items():
                 kernels[name] = {"us": sec * 1e6, "GBps": fb[name] * units / sec / 1e9,
                                  "TFLOPs": ffl[name] * units / sec / 1e12}
-            dom = max(ft, key=ft.get)
+            # the step calls the one-call form
+            dom = "loss_value_and_grad"
             kal = (dom, ft[dom], ffl[dom] * units, fb[dom] * units)
-            total_k = sum(ft.values())
-            note = ("the fused objective's two launches (plus their row sums) with the weight "
-                    "network's mixing weights; excludes the weight network and the noise draw")
+            total_k = ft[dom]
+            result["config"]["objective_state"] = (
+                "on chip (LDS): 16 lanes per sequence, one launch for value and gradient"
+                if on_chip else "through device memory: forward and backward launch")
+            note = ("kvae_kalman_loss_value_and_grad (value, d_a, d_alpha and the parameter "
+                    "gradients; with its row-sum launch) with the weight network's mixing "
+                    "weights; excludes the weight network and the noise draw; loss_forward / "
+                    "loss_backward are the two-call form of the same work, timed beside it")
         else:
             if not args.kernels_only:
                 kt = time_kernels(ssm, a, args.burn_in, iters=args.kernel_iters)
