@@ -20,7 +20,8 @@ class GraphedElboStep:
     ``(-objective).backward()`` for a fixed ``as_`` shape.
 
     ``step(as_)`` copies ``as_`` into the static input, replays the graph and
-    returns the objective (a tensor that the next replay overwrites).  After a
+    returns the objective (a tensor that the next replay overwrites; ``step.info`` is the
+    ``info`` dictionary of the captured call, whose tensors are overwritten alike).  After a
     replay the gradients are in ``p.grad`` of the module's parameters and in
     ``step.as_grad``; both are overwritten, not accumulated, by every replay
     (``p.grad`` is re-pointed at the graph's static tensors after each replay).
@@ -76,7 +77,8 @@ class GraphedElboStep:
     def _eager(self):
         self.ssm.zero_grad(set_to_none=True)
         self.static_as.grad = None
-        objective, _ = kalman_elbo(self.ssm, self.static_as, self._sc, **self._kwargs)
+        # (info: static tensors too, e.g. info["elbo_terms"]; every replay overwrites them)
+        objective, self.info = kalman_elbo(self.ssm, self.static_as, self._sc, **self._kwargs)
         # gradients of the loss -objective: a constant -1 as the upstream gradient
         # instead of a negation kernel, its adjoint and the seed fill
         if self._minus_one is None:

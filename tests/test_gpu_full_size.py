@@ -113,6 +113,84 @@ def _check_against_oracle(ssm, a, obj, info, g_a, draws, idx, burn_in):
     assert not failures, "; ".join(failures)
 
 
+def test_config2_step_as_benchmarked(monkeypatch):
+    """Exactly the step bench.py times by default: the fused objective (value and gradient in
+    one call, per-pair terms kept), captured and replayed as ONE HIP graph, T=20, B=4096, the
+    reference's default network (2 x 128 LSTM) on split-bf16 products.  A subset of sequences
+    through the float64 oracle must give the same per-pair terms and the same gradient
+    w.r.t. the observations; the objective must equal the sum of the terms; and every
+    parameter gradient must agree with the same step on exact fp32 products."""
+    import kalman_vae_amd.elbo as ke
+    from kalman_vae_amd import SampleControl
+    from kalman_vae_amd import _capi as capi
+    from kalman_vae_amd.graphed import GraphedElboStep
+    T, B, n, p, K, burn_in = 20, 4096, 4, 2, 3, 3
+    ssm = _model(n, p, K, "lstm", seed=5, train=True)
+    assert ssm.weight_model.hidden_dim == 128 and ssm.weight_model.num_layers == 2
+    ssm.fused_loss = ssm.fused_loss_terms = True
+    g = torch.Generator().manual_seed(16)
+    a = (0.7 * torch.randn(T, B, p, generator=g)).to(DEV)
+    eps = torch.randn(T, B, n, generator=g).to(DEV)     # the ELBO sample's noise, fixed
+
+    def fixed(shape, dtype, device):
+        assert tuple(shape) == (T, B, n)
+        return eps
+
+    monkeypatch.setattr(ke, "_standard_normal", fixed)
+    lib = capi.load()
+    assert lib.kvae_lstm128_get_precision() == 1
+    kw = dict(burn_in=burn_in, sequence_operation="sum", batch_operation="sum")
+    step = GraphedElboStep(ssm, a, SampleControl(), **kw)
+    obj = step(a)
+    torch.cuda.synchronize()
+    assert step.info["filter_means"] is None            # the fused path: nothing materialised
+    obs, trans, post = step.info["elbo_terms"]
+    grads = {k: v.grad.detach().clone() for k, v in ssm.named_parameters() if v.grad is not None}
+    g_a = step.as_grad.detach().clone()
+    failures = []
+    idx = torch.randperm(B, generator=g)[:40]
+    zeros = (torch.zeros(T, B, n, device=DEV), torch.zeros(T, B, p, device=DEV))
+    oobj, oinfo, a64 = _oracle_subset(ssm, a, idx, zeros, eps, burn_in=burn_in)
+    for name, got in (("obs", obs), ("trans", trans), ("post", post)):
+        e = rel_err(got[:, idx], oinfo["elbo_" + name])
+        if not e < TOL:
+            failures.append(f"elbo_{name}: {e:.2e}")
+    (og,) = torch.autograd.grad(oobj, [a64])
+    e = rel_err(g_a[:, idx], -og)                        # the graph differentiates -objective
+    if not e < TOL:
+        failures.append(f"d(-objective)/d a: {e:.2e}")
+    total = obs.double().sum() + trans.double().sum() - post.double().sum()
+    e = abs(float(obj) - float(total)) / abs(float(total))
+    if not e < 1e-5:
+        failures.append(f"objective vs sum of terms: {e:.2e}")
+    # a second replay gives the same numbers (fixed noise): nothing is left over between replays
+    obj_again = float(step(a))
+    torch.cuda.synchronize()
+    if obj_again != float(obj):
+        failures.append(f"replay changed the objective: {obj_again} vs {float(obj)}")
+    # the same step with every weight-network product on fp32 matrix instructions
+    lib.kvae_lstm128_set_precision(0)
+    try:
+        exact = GraphedElboStep(ssm, a, SampleControl(), **kw)
+        obj32 = exact(a)
+        torch.cuda.synchronize()
+        e = abs(float(obj32) - float(obj)) / abs(float(obj))
+        if not e < 1e-5:
+            failures.append(f"objective, split vs exact products: {e:.2e}")
+        for k, v in ssm.named_parameters():
+            if v.grad is None:
+                continue
+            e = rel_err(grads[k], v.grad)
+            if not e < TOL:
+                failures.append(f"d/d {k}, split vs exact products: {e:.2e}")
+        e = rel_err(g_a, exact.as_grad)
+        if not e < TOL:
+            failures.append(f"d/d a, split vs exact products: {e:.2e}")
+    finally:
+        lib.kvae_lstm128_set_precision(1)
+    assert not failures, "; ".join(failures)
+
+
 def test_config2_full_batch_subset_and_permutation(monkeypatch):
     T, B, n, p, K, burn_in = 20, 4096, 4, 2, 3, 3
     ssm = _model(n, p, K, "lstm", seed=5, train=True)
