@@ -65,6 +65,20 @@ def build_case(ref, name, cfg):
         init_transition_reg_weight=cfg.get("init_reg", 0.9),
         init_observation_reg_weight=cfg.get("init_reg", 0.9),
     )
+    if cfg.get("seeded_lstm", False):
+        # the reference's default network (2 x 128) has 200 k parameters: its large matrices
+        # are regenerated from a seed on both sides instead of being stored, and of their
+        # gradients every 16th element and the sum are kept
+        sys.path.insert(0, os.path.dirname(HERE))
+        from golden_util import seeded_tensor
+        seeded = {}
+        with torch.no_grad():
+            for k, v in ssm.weight_model.named_parameters():
+                if v.numel() >= 4096:
+                    bound = 1.0 / float(cfg["hidden_dim"]) ** 0.5
+                    v.copy_(seeded_tensor("weight_model." + k, v.shape, cfg["seed"], bound))
+                    seeded["weight_model." + k] = [list(v.shape), bound]
+        cfg = dict(cfg, seeded=seeded)
     if cfg.get("general_noise", False):
         with torch.no_grad():
             ssm._mat_Q_L.copy_(0.6 * torch.eye(n) + 0.15 * torch.randn(n, n))
@@ -180,7 +194,8 @@ def build_case(ref, name, cfg):
     data["in.m0"] = _np(ssm.initial_state_mean)
     data["in.P0"] = _np(ssm.initial_state_covariance)
     for k, v in ssm.state_dict().items():
-        data["sd." + k] = _np(v)
+        if k not in cfg.get("seeded", {}):
+            data["sd." + k] = _np(v)
     data["eps.filter_state"] = _np(f_eps_s)
     data["eps.filter_obs"] = _np(f_eps_o)
     data["eps.smooth_state"] = _np(s_eps_s)
@@ -199,7 +214,12 @@ def build_case(ref, name, cfg):
         for k in out_names:
             data["cot." + k] = _np(cots[k])
     for (k, _), gval in zip(params.items(), grads):
-        if gval is not None:
+        if gval is None:
+            continue
+        if k in cfg.get("seeded", {}):
+            data["gradsub." + k] = _np(gval.reshape(-1)[::16])
+            data["gradsum." + k] = _np(gval.sum())
+        else:
             data["grad." + k] = _np(gval)
     if cfg.get("store_f32", False):
         # large-state fixtures: computed in float64, stored in float32 (inputs are
@@ -278,6 +298,10 @@ def cases():
               objective_only=True, burn_in=3, T=20, B=4, identity_noise_via_setter=True)
     c["train_lstm_f64"] = dict(tr, net="lstm", seed=30)
     c["train_lstm_f32"] = dict(tr, net="lstm", seed=30, dtype="float32")
+    # the reference's default weight network (hidden_dim 128, two layers)
+    c["train_lstm128_f64"] = dict(tr, net="lstm", seed=35, hidden_dim=128, seeded_lstm=True, B=6)
+    c["train_lstm128_f32"] = dict(tr, net="lstm", seed=35, hidden_dim=128, seeded_lstm=True, B=6,
+                                  dtype="float32")
     c["train_mlp_warmup_f64"] = dict(tr, net="mlp", seed=31, learn_weight_model=False, T=9)
     c["train_general_f64"] = dict(base, net="lstm", seed=32, train_mode=True,
                                   state_transition="sample", observation="sample",

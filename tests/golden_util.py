@@ -26,6 +26,9 @@ class Golden:
         self.stored_f32 = bool(self.cfg.get("store_f32", False))
         self.t = {k: (v.to(self.dtype) if v.is_floating_point() else v)
                   for k, v in self.t.items()}
+        # large parameter tensors that the fixture regenerates from a seed instead of storing
+        for k, (shape, bound) in self.cfg.get("seeded", {}).items():
+            self.t["sd." + k] = seeded_tensor(k, shape, self.cfg["seed"], bound).to(self.dtype)
 
     def __getitem__(self, key):
         return self.t[key]
@@ -51,6 +54,22 @@ class Golden:
         ob = self.cfg["observation"] == "sample"
         return (self.t[f"eps.{which}_state"] if st else None,
                 self.t[f"eps.{which}_obs"] if ob else None)
+
+
+def grad_mismatch(g, key, got, tol):
+    """Relative error of gradient ``got`` against fixture ``g``'s record of parameter ``key``:
+    the whole tensor, or (seeded parameters) every 16th element and the sum.  None when the
+    fixture holds no gradient for it."""
+    if g.has("grad." + key):
+        return rel_err(got, g["grad." + key])
+    if g.has("gradsub." + key):
+        flat = got.detach().reshape(-1)
+        e_sub = rel_err(flat[::16], g["gradsub." + key])
+        # the sum against the size of its terms (it cancels)
+        e_sum = float(abs(flat.double().sum().cpu() - g["gradsum." + key].double())
+                      / flat.double().abs().sum().cpu().clamp_min(1e-30))
+        return max(e_sub, e_sum)
+    return None
 
 
 def rel_err(x, ref):

@@ -4,7 +4,7 @@ oracle/kalman_oracle.py and compare all outputs and gradients."""
 import pytest
 import torch
 
-from golden_util import Golden, golden_names, rel_err
+from golden_util import Golden, golden_names, grad_mismatch, rel_err
 from oracle import kalman_oracle as O
 
 OUT_MAP = {  # oracle info key -> fixture key
@@ -73,8 +73,8 @@ def test_oracle_matches_reference(name):
             loss = loss + (g["cot." + gk] * info[ok]).sum()
     grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
     for (k, _), gv in zip(params.items(), grads):
-        if g.has("grad." + k):
+        if g.has("grad." + k) or g.has("gradsub." + k):
             assert gv is not None, k
-            assert rel_err(gv, g["grad." + k]) < tol * 10, (k, rel_err(gv, g["grad." + k]))
+            assert grad_mismatch(g, k, gv, tol) < tol * 10, (k, grad_mismatch(g, k, gv, tol))
         else:
             assert gv is None or float(gv.abs().max()) == 0.0, k
