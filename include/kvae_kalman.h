@@ -246,7 +246,8 @@ int kvae_elbo_backward(const kvae_dims *d, const kvae_elbo_bwd *io,
  * Three kernel forms serve these calls, chosen from the dimensions (KVAE_SEQ_LANES=1|4|16
  * in the environment forces one): one lane per sequence (large batches), four lanes per
  * sequence, and 16 lanes per sequence with the per-step state in LDS (float, n and p up to
- * 4, T <= 36, up to 8192 sequences).  In the last form the forward call writes nothing to
+ * 4, T <= 35, and no more sequences than are resident on the device at once: 4096 at
+ * T = 20 on 256 compute units).  In the last form the forward call writes nothing to
  * `saved` (kvae_loss_saved_bytes() is then 256) and the backward call recomputes the
  * forward pass on chip instead of reading it back.                                 */
 typedef struct {
@@ -284,7 +285,7 @@ int kvae_kalman_loss_backward(const kvae_dims *d, const kvae_loss_bwd *io, void 
  * io->fwd.terms) and everything kvae_kalman_loss_backward writes, for the cotangents in
  * io->g_scale (NULL = 1 for each of the three totals, i.e. the gradient of out[3]; a caller
  * that learns the real cotangent later multiplies by it: the gradient is linear in it).
- * While a sequence's per-step state fits on chip (float, n and p up to 4, T <= 36, a modest
+ * While a sequence's per-step state fits on chip (float, n and p up to 4, T <= 35, a modest
  * batch: 16 lanes per sequence, state in LDS) this is ONE launch that reads a, alpha, eps and
  * writes d_a, d_alpha and per-wavefront sums: no mean or covariance goes through device
  * memory and io->fwd.saved is not touched.  Otherwise it is the two calls above in a row

@@ -520,7 +520,7 @@ int kvae_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* wo
 
 int kvae_filter_smooth_forward(const kvae_dims* d, const kvae_filter_fwd* f,
                                const kvae_smooth_fwd* s, void* stream) {
-    if (!f || !s || !f->mat_As || !f->mat_Cs || s->mean_filt != f->mean_filt ||
+    if (!dims_ok(d) || !f || !s || !f->mat_As || !f->mat_Cs || s->mean_filt != f->mean_filt ||
         s->cov_filt != f->cov_filt || s->mean_pred != f->mean_pred ||
         s->cov_pred != f->cov_pred || s->mat_As != f->mat_As || s->mat_Cs != f->mat_Cs)
         return KVAE_E_BADARG;

@@ -107,15 +107,18 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const R* partial, long
     }
 }
 
-// Which form runs a call: 16 lanes per sequence (row form, loss_row_kernels.hip) while that
-// gives at most two wavefronts per SIMD, four lanes per sequence (quad form) while one lane
-// per sequence would leave SIMDs without a wavefront (the chip has 1024), else one lane per
-// sequence.  KVAE_SEQ_LANES=1|4|16 forces a form where it exists (tests, timing).  The row
-// form needs its per-step state to fit LDS (T <= 36) and exists for float only; its forward
-// call writes nothing into `saved` and its backward call reads nothing from it, so both
-// calls of a pair must take the same decision: it depends on the dimensions and the
-// environment only.
-constexpr long LOSS_ROW_MAX_B = 8192;
+// Which form runs a call: 16 lanes per sequence (row form, loss_row_kernels.hip) while all of
+// its workgroups are resident at once, four lanes per sequence (quad form) while one lane per
+// sequence would leave SIMDs without a wavefront (the chip has 1024), else one lane per
+// sequence.  The row form's workgroups hold their sequences' per-step state in LDS, which
+// bounds how many a compute unit takes (four at T = 20: 4096 sequences on 256 compute units);
+// a second round of workgroups doubles its time, and from there the quad form is faster
+// (T = 20: 75 / 160 us at 4096 / 5120 sequences against 131 / 136 us; T = 8: 49 / 81 us at
+// 8192 / 12288 against 63 / 68 us).  KVAE_SEQ_LANES=1|4|16 forces a form where it exists
+// (tests, timing).  The row form needs its per-step state to fit 64 KB of LDS (T <= 35 with
+// the gradient) and exists for float only; its forward call writes nothing into `saved` and its
+// backward call reads nothing from it, so both calls of a pair must take the same decision:
+// it depends on the dimensions, the environment and the current device only.
 inline int loss_form(const kvae_dims* d) {
     const char* e = getenv("KVAE_SEQ_LANES");
     const int forced = e ? atoi(e) : 0;
@@ -124,7 +127,7 @@ inline int loss_form(const kvae_dims* d) {
     if (forced == 16 && row_ok) return 16;
     if (forced == 4 && quad_ok) return 4;
     if (forced == 1) return 1;
-    if (forced == 0 && row_ok && d->B <= LOSS_ROW_MAX_B) return 16;
+    if (forced == 0 && row_ok && d->B <= row_loss_resident_sequences(d->T)) return 16;
     if (quad_ok && d->B < 32768) return 4;
     return 1;
 }

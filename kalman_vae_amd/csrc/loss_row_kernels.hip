@@ -11,6 +11,7 @@
 #include "../../include/kvae_kalman.h"
 #include "kalman_row.h"
 #include "launch_common.h"
+#include "device_info.h"
 #include "wave_api.h"
 
 namespace kvae {
@@ -308,6 +309,16 @@ int row_backward(const kvae_dims* d, const kvae_loss_bwd* io, void* ws, size_t w
 #endif
 
 long row_loss_rows(long B) { return (B + ROW_SEQS - 1) / ROW_SEQS; }
+
+// Sequences whose workgroups are all resident at once on the current device.  A compute unit
+// holds as many workgroups as its 160 KB of LDS have room for (2 KB granules), and two
+// wavefronts per SIMD are as far as this form was measured to gain.
+long row_loss_resident_sequences(int T) {
+    const size_t lds = (row_lds_bytes<true>(T) + 2047) / 2048 * 2048;
+    long per_cu = (long)(160 * 1024 / lds);
+    if (per_cu > 8) per_cu = 8;
+    return (long)ROW_SEQS * device_compute_units() * per_cu;
+}
 
 int row_loss_supported(int n, int p, int K, int dtype, int T, int grad) {
     if (dtype != KVAE_F32) return 0;

@@ -1,7 +1,10 @@
-// Helpers shared by the LSTM translation units (lstm_kernels.hip, lstm_resident.hip).
+// Helpers shared by the LSTM translation units (lstm_kernels.hip, lstm_resident.hip,
+// lstm_step_fused.hip, rowstream_matmul.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "device_info.h"
 
 namespace kvae {
 

@@ -919,19 +919,7 @@ int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const
 using namespace kvae;
 
 // workgroups that are resident at once: one per compute unit (each takes all registers)
-static int resident_workgroups() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            cus > 0)
-            n = cus;
-        else
-            n = 256;
-    }
-    return n;
-}
+static int resident_workgroups() { return device_compute_units(); }
 
 // 0: exact fp32 matrix instructions; 1: three bf16 instructions per product (default).
 // KVAE_LSTM_PRECISION=fp32 in the environment selects 0 at the first call.

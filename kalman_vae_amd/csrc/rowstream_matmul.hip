@@ -229,13 +229,7 @@ int kvae_rowstream_matmul(long M, int K, int N, const void* X, const void* W, co
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) |
          reinterpret_cast<uintptr_t>(Y)) & 15)
         return KVAE_E_BADARG;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess &&
-               hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-               n > 0) ? n : 256;
-    }
+    const int cus = device_compute_units();
     const long tiles = (M + 15) / 16;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
 #define KVAE_RS_LAUNCH(K_, N_, F_)                                                          \

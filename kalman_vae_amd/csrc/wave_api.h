@@ -31,6 +31,7 @@ size_t loss_workspace_bytes(const kvae_dims* d, int op);
 // state in LDS, fp32, n and p up to 4).  row_loss_backward recomputes the forward pass and so
 // needs nothing saved; with_value it also writes the forward call's outputs.
 long row_loss_rows(long B);
+long row_loss_resident_sequences(int T);
 int row_loss_supported(int n, int p, int K, int dtype, int T, int grad);
 size_t row_loss_workspace_bytes(const kvae_dims* d);
 int row_loss_forward(const kvae_dims* d, const kvae_loss_fwd* io, void* ws, size_t ws_bytes,

@@ -1,0 +1,50 @@
+"""Build-time audit of the one-step LSTM layer kernel's device code (no GPU needed: hipcc
+cross-compiles).  The kernel pins its upper-layer weights to accumulation registers with an asm
+constraint; when the register allocator evicts such a vector it saves the pieces apart and, with
+this compiler, does not restore all of them (tools/exp/orphan_spills.py describes the pattern).
+The shipped objects must be free of it, and the checker must still find it in the form that is
+known to have it."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kalman_vae_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+CHECKER = os.path.join(ROOT, "tools", "exp", "orphan_spills.py")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-S", "--cuda-device-only"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+
+
+def listing(tmp_path, name, extra):
+    out = str(tmp_path / (name + ".s"))
+    subprocess.run([HIPCC, *FLAGS, *extra, "-o", out, os.path.join(CSRC, "lstm_step_fused.hip")],
+                   check=True, stderr=subprocess.DEVNULL)
+    return out
+
+
+def check(path, *args):
+    return subprocess.run([sys.executable, CHECKER, path, *args], capture_output=True, text=True)
+
+
+def test_upper_layer_object_has_no_spill(tmp_path):
+    """The instances with pinned weights (compiled as the Makefile compiles them)."""
+    r = check(listing(tmp_path, "upper", ["-DKVAE_SF_UPPER", "-mllvm", "-amdgpu-mfma-vgpr-form"]), "--any")
+    assert r.returncode == 0, r.stdout
+
+
+def test_lower_layer_object_restores_what_it_spills(tmp_path):
+    r = check(listing(tmp_path, "lower", []))
+    assert r.returncode == 0, r.stdout
+
+
+def test_checker_finds_the_unrestored_piece_in_the_pinned_lower_layer(tmp_path):
+    """The reproducer: with the lower layer's weights pinned too, one dword of an evicted weight
+    vector is saved to a register that nothing reads again.  Should a later compiler restore it,
+    this test fails and the pin can be tried on the lower layer again."""
+    r = check(listing(tmp_path, "pinned", ["-DKVAE_SF_PIN_LOWER=1"]))
+    assert r.returncode == 1 and "never read afterwards" in r.stdout, r.stdout

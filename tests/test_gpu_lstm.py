@@ -398,3 +398,61 @@ def test_layer_step_with_projection_in_kernel_matches_torch(B, carried, P):
     assert lib.kvae_lstm128_step_fused(B, 3, xs.data_ptr(), wx.data_ptr(), None, None,
                                        whht.data_ptr(), bias.data_ptr(), h.data_ptr(),
                                        c.data_ptr(), None) == -2
+
+
+@pytest.mark.parametrize("P", [0, 1, 2])
+@pytest.mark.parametrize("B,carried", [(16 * 3 * 256, True), (16 * 3 * 256 + 5, True),
+                                       (16 * 2 * 256, False), (16 * 200, True)])
+def test_layer_step_every_entry_of_each_first_tile(B, carried, P):
+    """kvae_lstm128_step_fused entry by entry against float64, with the first tile of every
+    tile walker looked at apart: that tile takes the kernel's prologue path (accumulators and
+    operands freshly placed), the one where a wrongly restored operand register shows.  A
+    maximum over millions of entries hides a single wrong value of ordinary size, so every entry
+    has its own bound; three launches on the same inputs must agree bit for bit."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    torch.manual_seed(7 * B + P)
+    dev = torch.device("cuda:0")
+    H = 128
+    in_dim = P if P > 0 else H
+    lstm = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev)
+    x = torch.randn(B, in_dim, device=dev)
+    hp, cp = 0.5 * torch.randn(B, H, device=dev), 0.5 * torch.randn(B, H, device=dev)
+    ref64 = torch.nn.LSTM(in_dim, H, num_layers=1).to(dev).double()
+    ref64.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+        state = (hp[None].double(), cp[None].double()) if carried else None
+        _, (hn, cn) = ref64(x[None].double(), state)
+    hn, cn = hn[0], cn[0]
+    w_ih = lstm.weight_ih_l0.detach()
+    wx = w_ih.t().contiguous() if P == 0 else w_ih.contiguous()
+    whht = lstm.weight_hh_l0.detach().t().contiguous()
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().contiguous()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (B + 15) // 16
+    walkers = min(tiles, cus) if P > 0 else 8 * max(1, min(cus // 16, (tiles + 7) // 8))
+    first_rows = min(B, 16 * walkers)              # tile k of walker w is tile w + k * walkers
+    outs = []
+    for _ in range(3):
+        h = torch.full((B, H), float("nan"), device=dev)
+        c = torch.full((B, H), float("nan"), device=dev)
+        rc = lib.kvae_lstm128_step_fused(B, P, x.data_ptr(), wx.data_ptr(),
+                                         hp.data_ptr() if carried else None,
+                                         cp.data_ptr() if carried else None, whht.data_ptr(),
+                                         bias.data_ptr(), h.data_ptr(), c.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append((h, c))
+    for h, c in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(c, outs[0][1])
+    h, c = outs[0]
+    # split products: an absolute error of about 1e-6 times the terms of a gate sum (N(0,1)
+    # inputs: up to ~1e-5 on a value in (-1, 1)); an operand dword taken from a stale register
+    # moved entries by 1e-4 and more
+    bound = 4e-5
+    eh, ec = (h.double() - hn).abs(), (c.double() - cn).abs()
+    wrong = ((eh > bound) | (ec > bound) | torch.isnan(eh) | torch.isnan(ec))
+    where = wrong.nonzero()[:8].tolist()
+    assert not where, (f"{int(wrong.sum())} wrong entries, {int(wrong[:first_rows].sum())} of them in "
+                       f"first tiles; (row, unit): {where}")

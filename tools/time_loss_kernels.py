@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HIP-event durations of the fused objective's two calls and of the six separate kernels
-on the same problem.  python tools/time_loss_kernels.py [B ...]"""
+on the same problem.  python tools/time_loss_kernels.py [B ...]   (KVAE_TIME_T=<steps>, default 20)"""
 import ctypes as C
 import os
 import sys
@@ -28,7 +28,7 @@ def timed(fn, iters=30):
 
 
 def main():
-    T, n, p, K = 20, 4, 2, 3
+    T, n, p, K = int(os.environ.get("KVAE_TIME_T", "20")), 4, 2, 3
     dt = torch.float32
     lib = capi.load()
     be = Backend("hip")
@@ -58,7 +58,7 @@ def main():
                                                                ws_v.data_ptr(), nb_v, stream))
         units = T * B
         flops = 5.6e3 * units
-        print(f"B={B} lanes={os.environ.get('KVAE_SEQ_LANES', 'auto')}: value_and_grad {tv:.1f} us"
+        print(f"T={T} B={B} lanes={os.environ.get('KVAE_SEQ_LANES', 'auto')}: value_and_grad {tv:.1f} us"
               f" = {units / tv * 1e6 / 1e9:.2f} G seq-steps/s,"
               f" {flops / tv / 1e6 / 157.3 * 100:.1f} % of fp32 VALU peak", flush=True)
         print(f"B={B}: loss_forward {tf:.1f} us, loss_backward {tb:.1f} us, total {tf + tb:.1f} us"
