@@ -351,6 +351,34 @@ def _resident_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w
     return out
 
 
+class _ProductForm:
+    """The library's product form (0: exact fp32 matrix instructions, 1: three bf16
+    instructions per product) is a process-wide setting read at every launch.  A backward pass
+    must multiply in the form its forward pass used: the saved gates came from that form.  The
+    autograd nodes below record the form at forward time and run their backward launches
+    inside ``with _ProductForm(form)``, which sets it for the launches and puts back whatever
+    was set before (launches read the setting on the host, when they are issued)."""
+
+    def __init__(self, form):
+        self.form, self.prev = int(form), None
+
+    @staticmethod
+    def current():
+        return int(capi.load().kvae_lstm128_get_precision())
+
+    def __enter__(self):
+        lib = capi.load()
+        self.prev = int(lib.kvae_lstm128_get_precision())
+        if self.prev != self.form:
+            lib.kvae_lstm128_set_precision(self.form)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.form:
+            capi.load().kvae_lstm128_set_precision(self.prev)
+        return False
+
+
 class ResidentLSTM2Function(torch.autograd.Function):
     """Two layers, hidden size 128, one launch per layer and direction with the layer's
     recurrent matrix resident in registers (kvae_lstm128_forward / _backward).  Layer 1's
@@ -361,6 +389,7 @@ class ResidentLSTM2Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
         x = x.contiguous()
+        ctx.product_form = _ProductForm.current()
         gates0, h0, c0, gates1, h1, c1 = _resident_forward(x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1,
                                                            w_hh1, b_ih1, b_hh1)
         ctx.save_for_backward(x, gates0, h0, c0, gates1, h1, c1, w_ih0, w_hh0, w_ih1, w_hh1)
@@ -370,14 +399,16 @@ class ResidentLSTM2Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_h1, _dh0, _dc0, _dc1):
-        return _resident_backward(*ctx.saved_tensors, g_h1=g_h1.contiguous())
+        with _ProductForm(ctx.product_form):
+            return _resident_backward(*ctx.saved_tensors, g_h1=g_h1.contiguous())
 
 
 class ResidentLSTM2HeadFunction(torch.autograd.Function):
     """ResidentLSTM2Function followed by the softmax head alpha = softmax(h1 W^T + b) as ONE
     autograd node: the head's adjoint runs inside the upper layer's backward kernel
     (kvae_lstm128_backward_head), which neither reads a gradient w.r.t. h1 nor needs the
-    head's own backward launch and reduction.  K in 2..4, split product form."""
+    head's own backward launch and reduction.  K in 2..4, either product form (the backward
+    pass runs in the one the forward pass used)."""
 
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_head, b_head,
@@ -386,6 +417,7 @@ class ResidentLSTM2HeadFunction(torch.autograd.Function):
         x = x.contiguous()
         T, B, _ = x.shape
         H, K = 128, w_head.shape[0]
+        ctx.product_form = _ProductForm.current()
         gates0, h0, c0, gates1, h1, c1 = _resident_forward(x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1,
                                                            w_hh1, b_ih1, b_hh1)
         wc = w_head.contiguous()
@@ -410,7 +442,8 @@ class ResidentLSTM2HeadFunction(torch.autograd.Function):
         T, B, _ = x.shape
         K = wc.shape[0]
         g = g_alpha.contiguous().view(-1, K)[ctx.lead_rows:]
-        grads = _resident_backward(*saved, head=(out[ctx.lead_rows:], g, wc))
+        with _ProductForm(ctx.product_form):
+            grads = _resident_backward(*saved, head=(out[ctx.lead_rows:], g, wc))
         return grads + (None,)
 
 

@@ -34,8 +34,18 @@ class FlatGradBucket:
     the flat buffer, the all-reduce averages it in place (``ReduceOp.AVG`` where the
     backend has it: no separate division), and every parameter's ``.grad`` is re-pointed
     at its slice of the buffer -- no copy back.  Parameters that received no gradient keep
-    ``grad = None`` (the optimizer skips them, as on a single device) and their slices
-    stay zero.  ``async_op=True`` returns the collective's work handle: the reduction runs
+    ``grad = None`` (the optimizer skips them, as on a single device); their slices are
+    zeroed before the reduction, whatever an earlier step left there.
+
+    All ranks must produce gradients for the SAME parameters in a step: a rank without a
+    gradient for a parameter would keep ``grad = None`` while the others step on it, and the
+    replicas would drift apart.  One flag per parameter rides at the end of the buffer
+    through the same all-reduce; a flag that comes back neither 0 nor "all ranks" raises
+    ``RuntimeError`` -- at once for a blocking reduction, at the next ``wait()`` /
+    ``all_reduce()`` / ``check()`` for an asynchronous one (its flags are copied to the host
+    without blocking).
+
+    ``async_op=True`` returns the collective's work handle: the reduction runs
     on the backend's own stream, and the caller waits on the handle before reading the
     gradients (or before the next ``all_reduce``).
     """
@@ -46,27 +56,88 @@ class FlatGradBucket:
             raise ValueError("no trainable parameters")
         p0 = self.params[0]
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.storage = torch.zeros(self.numel + len(self.params), dtype=p0.dtype, device=p0.device)
+        self.flat = self.storage[:self.numel]           # the gradients
+        self.flags = self.storage[self.numel:]          # 1 where this rank has a gradient
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self._pending = None
+        self._pattern = None            # which parameters had a gradient at the last pack()
+        self._flag_src = None
+        self._flags_stale = True        # the buffer's flags are not this rank's pattern
+        self._clean = [True] * len(self.params)   # slice known to be all zero
+        self._host_flags = None
+        self._unchecked = None          # (event or None, pattern, scale, world) of a reduction
 
     def wait(self):
         """Block the current stream until the last asynchronous all-reduce is done."""
         if self._pending is not None:
             self._pending.wait()
             self._pending = None
+            if self._unchecked is not None and self._unchecked[0] is None:
+                # flags to the host behind the reduction, without blocking; looked at later
+                if self._host_flags is None:
+                    self._host_flags = torch.empty(len(self.params), dtype=self.flags.dtype,
+                                                   pin_memory=self.flags.is_cuda)
+                self._host_flags.copy_(self.flags, non_blocking=True)
+                event = None
+                if self.flags.is_cuda:
+                    event = torch.cuda.Event()
+                    event.record()
+                self._unchecked = (event or True,) + self._unchecked[1:]
+                return
+        self.check()
+
+    def check(self):
+        """Raise if the ranks of the last finished reduction disagreed on which parameters
+        received a gradient."""
+        if self._unchecked is None or self._unchecked[0] is None:
+            return
+        event, pattern, scale, world = self._unchecked
+        self._unchecked = None
+        if event is not True:
+            event.synchronize()
+        self._verify(self._host_flags.tolist(), pattern, scale, world)
+
+    @staticmethod
+    def _verify(got, pattern, scale, world):
+        bad = [i for i, (g, had) in enumerate(zip(got, pattern))
+               if abs(g - (scale if had else 0.0)) > 0.25 * scale / world]
+        if bad:
+            raise RuntimeError(
+                "data-parallel ranks disagree on which parameters received a gradient "
+                f"(parameter indices {bad[:8]}{' ...' if len(bad) > 8 else ''}): "
+                "every rank must produce gradients for the same parameters in a step")
 
     def pack(self):
-        """Gather the gradients that do not already live in the buffer (one launch)."""
-        src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        """Gather the gradients that do not already live in the buffer and this rank's flags
+        (one launch); zero the slices of parameters without a gradient."""
+        pattern = tuple(p.grad is not None for p in self.params)
+        src, dst, stale = [], [], []
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
             g = p.grad
-            if g is not None and g.data_ptr() != v.data_ptr():
-                src.append(g)
-                dst.append(v)
+            if g is None:
+                if not self._clean[i]:
+                    stale.append(v)
+                    self._clean[i] = True
+            else:
+                self._clean[i] = False
+                if g.data_ptr() != v.data_ptr():
+                    src.append(g)
+                    dst.append(v)
+        if pattern != self._pattern:
+            self._flag_src = torch.tensor([float(f) for f in pattern], dtype=self.flags.dtype,
+                                          device=self.flags.device)
+            self._pattern = pattern
+            self._flags_stale = True
+        if self._flags_stale:
+            src.append(self._flag_src)
+            dst.append(self.flags)
+            self._flags_stale = False
+        if stale:
+            torch._foreach_zero_(stale)
         if src:
             torch._foreach_copy_(dst, src)
 
@@ -79,25 +150,36 @@ class FlatGradBucket:
     def all_reduce(self, average=True, group=None, async_op=False):
         """Sum (or average) the gradients over all ranks, in place in the flat buffer."""
         self.wait()
+        self.check()
         self.pack()
         work = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world = dist.get_world_size(group)
             backend = dist.get_backend(group)
-            if self.flat.is_cuda and backend == "gloo":
+            blocking = True
+            if self.storage.is_cuda and backend == "gloo":
                 # gloo reduces host memory (its device path hangs on this ROCm build);
                 # only rehearsals and tests pair gloo with GPU tensors
-                host = self.flat.cpu()
+                host = self.storage.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
                 if average:
-                    host /= dist.get_world_size(group)
-                self.flat.copy_(host)
+                    host /= world
+                self.storage.copy_(host)
             elif backend == "nccl":
                 op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM
-                work = dist.all_reduce(self.flat, op=op, group=group, async_op=async_op)
+                work = dist.all_reduce(self.storage, op=op, group=group, async_op=async_op)
+                blocking = not (async_op and work is not None)
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(self.storage, op=dist.ReduceOp.SUM, group=group)
                 if average:
-                    self.flat.div_(dist.get_world_size(group))
+                    self.storage.div_(world)
+            scale = 1.0 if average else float(world)
+            self._flags_stale = not average       # a sum leaves "ranks with a gradient" there
+            # slices no rank wrote stay zero; after a disagreement (an error) nothing is known
+            if blocking:
+                self._verify(self.flags.tolist(), self._pattern, scale, world)
+            else:
+                self._unchecked = (None, self._pattern, scale, world)
         self.bind()
         if async_op and work is not None:
             self._pending = work

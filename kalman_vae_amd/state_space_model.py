@@ -86,6 +86,7 @@ class StateSpaceModel(nn.Module):
         # behaviour switches that have no counterpart in the reference
         self._matrix_cache = None   # see cached_matrices()
         self._noise_pool = None     # see _draw()
+        self._draw_log = None       # see _log_draws()
         self._defer_status = False  # kalman_elbo reads the status word once per step
         self.rng_parity = True      # draw noise exactly like the reference does
         # kalman_elbo: compute the objective with the one-launch-per-direction kernels that
@@ -203,8 +204,29 @@ class StateSpaceModel(nn.Module):
         pool = self._noise_pool
         if pool:
             assert tuple(pool[0].shape) == tuple(shape), (tuple(pool[0].shape), tuple(shape))
-            return pool.pop(0)
-        return _standard_normal(shape, dtype=like.dtype, device=like.device)
+            eps = pool.pop(0)
+        else:
+            eps = _standard_normal(shape, dtype=like.dtype, device=like.device)
+        if self._draw_log is not None:
+            self._draw_log.append(eps)
+        return eps
+
+    def _log_draws(self):
+        """Start recording what _draw hands out (a fused path draws all its noise before it
+        learns whether a kernel covers the call)."""
+        self._draw_log = []
+        return self._draw_log
+
+    def _keep_draws(self):
+        self._draw_log = None
+
+    def _undo_draws(self, log):
+        """The path that drew `log` did not run: queue its tensors, in order, for the path that
+        runs instead.  Both draw the same shapes in the same order (the reference's), so the
+        generator is consumed once and the results are those of the reference's draw order."""
+        self._draw_log = None
+        if log:
+            self._noise_pool = list(log) + list(self._noise_pool or [])
 
     def _finish(self, device):
         # the status bits are OR-accumulated on the device: a caller that runs several
@@ -281,27 +303,36 @@ class StateSpaceModel(nn.Module):
                 and F.masked_mlp_grad_supported(layers[0].out_features, self.z_dim, self.a_dim,
                                                 self.K, as_.dtype)):
             # two-layer perceptron under autograd: one launch per direction
+            log = self._log_draws()
             out = F.masked_filter_mlp_grad(
                 as_, mask, layers[0], layers[1], A_K, C_K, Q, R, self.initial_state_mean,
                 self.initial_state_covariance, *self._filter_draws_split(as_, state_noise,
                                                                           obs_noise, L_Q, L_R),
                 symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
             if out is not None:
+                self._keep_draws()
                 return out[:7] + (out[7][:T],)
+            self._undo_draws(log)
         if (not torch.is_grad_enabled() and as_.is_cuda
                 and F.impute_supported(self.z_dim, self.a_dim, self.K, as_.dtype, as_.device)):
             layers = getattr(self.weight_model, "layers", None)
             if (layers is not None and len(layers) == 2 and self.in_kernel_weight_network
                     and F.masked_mlp_fits(layers[0].out_features, self.a_dim, self.K, as_.dtype)):
                 # two-layer perceptron: the network runs inside the filter kernel
+                log = self._log_draws()
                 fast = self._filter_masked_mlp(as_, mask, state_noise, obs_noise, symmetrize,
                                                L_Q, L_R, layers)
                 if fast is not None:
+                    self._keep_draws()
                     return fast
+                self._undo_draws(log)
+            log = self._log_draws()
             fast = self._filter_masked_inference(as_, mask, state_noise, obs_noise, symmetrize,
                                                  w, m_pred, P_pred, L_Q, L_R)
             if fast is not None:
+                self._keep_draws()
                 return fast
+            self._undo_draws(log)
         A_t = mix(w, A_K)
         out = {k: [] for k in ("m", "P", "mn", "Pn", "A", "C", "aw", "w")}
         for t in range(T):
@@ -479,6 +510,7 @@ class StateSpaceModel(nn.Module):
         if (as_.is_cuda and (mask is None or in_kernel)
                 and F.rollout_supported(self.z_dim, self.a_dim, self.K, as_.dtype)):
             self.weight_model.clear_hidden_state()
+            log = self._log_draws()
             with self.cached_matrices():
                 common = (self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R,
                           self.initial_state_mean, self.initial_state_covariance)
@@ -506,8 +538,12 @@ class StateSpaceModel(nn.Module):
                         want=("a_w", "as_resampled"))
                     filter_as = out["a_w"] if out is not None else None
             if out is not None:
+                self._keep_draws()
                 self._finish(as_.device)
                 return filter_as, out["as_resampled"]
+            # no kernel for this call after all: the two calls below are served the noise
+            # already drawn, in the order they ask for it
+            self._undo_draws(log)
         out = self.kalman_filter(as_, sample_control, observation_mask=observation_mask,
                                  symmetrize_covariance=symmetrize_covariance)
         smoothed = self.kalman_smooth(as_, *out[:6], sample_control=sample_control,

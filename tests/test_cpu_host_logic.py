@@ -271,3 +271,30 @@ def test_stepping_network_applies_only_on_the_gpu():
         steps = torch.cat([net(x[t:t + 1]) for t in range(5)])
     assert torch.allclose(whole, steps, atol=1e-6)
     assert abs(float(whole.sum()) - 5 * 4) < 1e-4        # rows of softmax weights
+
+
+def test_undone_draws_are_served_again_in_order():
+    """Noise drawn by a path that then does not run is queued for the path that runs instead:
+    same tensors, same order, the generator consumed once."""
+    from kalman_vae_amd import StateSpaceModel
+    ssm = StateSpaceModel(2, 4, 3, "mlp", hidden_dim=8)
+    like = torch.zeros(1)
+    torch.manual_seed(3)
+    log = ssm._log_draws()
+    first = [ssm._draw((5, 4), like), ssm._draw((5, 2), like), ssm._draw((5, 4), like)]
+    assert len(log) == 3
+    ssm._undo_draws(log)
+    again = [ssm._draw((5, 4), like), ssm._draw((5, 2), like), ssm._draw((5, 4), like)]
+    assert all(x is y for x, y in zip(first, again)) and not ssm._noise_pool
+    fresh = ssm._draw((5, 4), like)
+    torch.manual_seed(3)
+    want = [torch.randn(5, 4), torch.randn(5, 2), torch.randn(5, 4), torch.randn(5, 4)]
+    for x, y in zip(first + [fresh], want):
+        assert torch.equal(x, y)
+    # a queue that was installed before (all the noise of a step, drawn at once) stays behind
+    ssm._noise_pool = [torch.ones(2, 2)]
+    log = ssm._log_draws()
+    ssm._draw((2, 2), like)
+    ssm._noise_pool = [torch.zeros(1, 1)]
+    ssm._undo_draws(log)
+    assert [tuple(t.shape) for t in ssm._noise_pool] == [(2, 2), (1, 1)]

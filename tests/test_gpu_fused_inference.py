@@ -130,3 +130,40 @@ def test_module_impute_equals_filter_then_smoother(net, masked, mode):
         filter_as, as_resampled = ssm.impute(a, sc, observation_mask=mask)
     assert rel_err(filter_as, out[6]) < 2e-6
     assert rel_err(as_resampled, smo[3]) < 2e-6
+
+
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("refused", [("filter_smooth_fused",),
+                                     ("filter_smooth_fused", "masked_filter_mlp"),
+                                     ("filter_smooth_fused", "masked_filter_mlp",
+                                      "impute_observation")])
+def test_refused_kernel_does_not_draw_twice(masked, refused, monkeypatch):
+    """A fused path draws its noise before it learns whether a kernel covers the call.  When
+    the kernel refuses (here: made to), the path that runs instead must be served the noise
+    already drawn, so that the generator is consumed once and in the reference's order: the
+    results and the generator's state afterwards equal those of the plain two calls."""
+    from kalman_vae_amd import SampleControl, StateSpaceModel
+    from kalman_vae_amd import functions as F
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    ssm = StateSpaceModel(2, 4, 3, "mlp", hidden_dim=16).to(dev)
+    ssm.train(True)
+    T, B = 9, 40
+    a = torch.randn(T, B, 2, device=dev)
+    mask = (torch.rand(T, B, device=dev) < 0.6).float() if masked else None
+    sc = SampleControl(encoder="mean", decoder="mean", state_transition="sample",
+                       observation="sample")
+    with torch.no_grad():
+        torch.manual_seed(11)
+        out = ssm.kalman_filter(a, sc, observation_mask=mask)
+        smo = ssm.kalman_smooth(a, *out[:6], sample_control=sc)
+        after = torch.randn(3, device=dev)
+        for name in refused:
+            monkeypatch.setattr(F, name, lambda *a_, **k_: None)
+        torch.manual_seed(11)
+        filter_as, as_resampled = ssm.impute(a, sc, observation_mask=mask)
+        after2 = torch.randn(3, device=dev)
+    assert rel_err(filter_as, out[6]) < 2e-6
+    assert rel_err(as_resampled, smo[3]) < 2e-6
+    assert torch.equal(after, after2)
+    assert not ssm._noise_pool and ssm._draw_log is None

@@ -456,3 +456,42 @@ def test_layer_step_every_entry_of_each_first_tile(B, carried, P):
     where = wrong.nonzero()[:8].tolist()
     assert not where, (f"{int(wrong.sum())} wrong entries, {int(wrong[:first_rows].sum())} of them in "
                        f"first tiles; (row, unit): {where}")
+
+
+@pytest.mark.parametrize("first", [1, 0])
+def test_backward_multiplies_in_the_form_its_forward_used(first):
+    """The product form is a process-wide setting; changing it between a forward pass and its
+    backward pass must not mix the two forms: the gradient equals, bit for bit, the one of a
+    run that never changed the setting, and the setting is left as the caller put it."""
+    import kalman_vae_amd.lstm_function as lf
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    T, B, p, K = 6, 48, 2, 3
+    lstm = torch.nn.LSTM(p, 128, num_layers=2).to(dev)
+    lin = torch.nn.Linear(128, K).to(dev)
+    x = torch.randn(T, B, p, device=dev, requires_grad=True)
+    w = torch.randn(T + 1, B, K, device=dev)
+    params = [x] + list(lstm.parameters()) + list(lin.parameters())
+    try:
+        assert lib.kvae_lstm128_set_precision(first) == 0
+        a1, _ = lf.fused_lstm_head(x, lstm, lin, True)
+        g_same = torch.autograd.grad((a1 * w).sum(), params)
+        a2, _ = lf.fused_lstm_head(x, lstm, lin, True)
+        assert lib.kvae_lstm128_set_precision(1 - first) == 0
+        g_switched = torch.autograd.grad((a2 * w).sum(), params)
+        assert lib.kvae_lstm128_get_precision() == 1 - first
+        for a, b in zip(g_same, g_switched):
+            assert torch.equal(a, b)
+        h1, _ = lf.fused_lstm(x, lstm)
+        assert lib.kvae_lstm128_set_precision(first) == 0
+        g3 = torch.autograd.grad((h1 * h1).sum(), params[:-2])
+        assert lib.kvae_lstm128_set_precision(1 - first) == 0
+        h2, _ = lf.fused_lstm(x, lstm)
+        g4 = torch.autograd.grad((h2 * h2).sum(), params[:-2])
+        assert torch.equal(h1, h2)
+        for a, b in zip(g3, g4):
+            assert torch.equal(a, b)
+    finally:
+        lib.kvae_lstm128_set_precision(1)

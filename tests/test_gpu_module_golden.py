@@ -204,6 +204,22 @@ def test_fused_objective_matches_reference_f32(name, monkeypatch):
     compare(g, obj, info, grads, 3e-4, fused=True)
 
 
+@pytest.mark.parametrize("name", [n for n in TRAIN if "lstm128" in n])
+def test_fused_objective_with_exact_fp32_network_products(name, monkeypatch):
+    """The reference's torch.nn.LSTM multiplies in fp32; the library's default is three bf16
+    matrix instructions per product.  With the exact-fp32 setting (what a caller who wants the
+    reference's product arithmetic selects) the same fixtures hold to the same bounds."""
+    from kalman_vae_amd import _capi as capi
+    lib = capi.load()
+    g = Golden(name)
+    assert lib.kvae_lstm128_set_precision(0) == 0
+    try:
+        obj, info, grads = run_module(g, torch.float32, monkeypatch, fused=True)
+    finally:
+        lib.kvae_lstm128_set_precision(1)
+    compare(g, obj, info, grads, 1e-4 if name.endswith("_f64") else 3e-4, fused=True)
+
+
 def test_fused_objective_falls_back_with_a_mask(monkeypatch):
     """With an observation mask the weights depend on the filter state: fused=True must
     take the step-by-step path and still return every tensor."""

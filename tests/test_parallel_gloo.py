@@ -241,3 +241,65 @@ def test_sharded_masked_imputation_matches_full_batch(tmp_path):
     want = _masked_filter_host(model, a, mask)
     assert got.shape == want.shape
     assert torch.equal(got, want)              # sequences are independent: bit-identical
+
+
+# -- two steps, with a parameter that stops receiving a gradient --------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _two_step_worker(rank, world, port, out, skip_on):
+    """Step 1: both parameters get a gradient on every rank.  Step 2: `w2` gets none on the
+    ranks in `skip_on`."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(3, dtype=torch.float64))
+    w2 = torch.nn.Parameter(torch.randn(2, dtype=torch.float64))
+    bucket = FlatGradBucket([w1, w2])
+    x = torch.arange(1.0, 4.0, dtype=torch.float64) * (rank + 1)
+    ((w1 * x).sum() + (w2 * (rank + 2.0)).sum()).backward()
+    bucket.all_reduce(average=True)
+    step1 = (w1.grad.clone(), w2.grad.clone())
+    w1.grad, w2.grad = None, None                      # zero_grad(set_to_none=True)
+    loss = (w1 * x * x).sum()
+    if rank not in skip_on:
+        loss = loss + (w2 * 5.0).sum()
+    loss.backward()
+    error = None
+    try:
+        bucket.all_reduce(average=True)
+    except RuntimeError as err:
+        error = str(err)
+    torch.save({"step1": step1, "w1": w1.grad, "w2": w2.grad, "w2_slice": bucket.views[1].clone(),
+                "error": error}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_parameter_without_gradient_on_every_rank_leaves_a_zero_slice(tmp_path):
+    """A parameter that had a gradient in step 1 and has none in step 2 (on all ranks): its
+    slice of the bucket must not carry step 1's average into step 2's reduction."""
+    out = str(tmp_path / "two")
+    mp.spawn(_two_step_worker, args=(2, _free_port(), out, (0, 1)), nprocs=2, join=True)
+    for rank in range(2):
+        got = torch.load(f"{out}.{rank}")
+        assert got["error"] is None
+        assert torch.equal(got["step1"][0], torch.tensor([1.5, 3.0, 4.5], dtype=torch.float64))
+        assert torch.equal(got["step1"][1], torch.full((2,), 2.5, dtype=torch.float64))
+        assert torch.equal(got["w1"], torch.tensor([2.5, 10.0, 22.5], dtype=torch.float64))
+        assert got["w2"] is None and float(got["w2_slice"].abs().max()) == 0.0
+
+
+def test_ranks_that_disagree_on_a_gradient_are_told_so(tmp_path):
+    """Rank 1 produces no gradient for a parameter that rank 0 steps on: both ranks raise
+    instead of letting the replicas drift apart."""
+    out = str(tmp_path / "two")
+    mp.spawn(_two_step_worker, args=(2, _free_port(), out, (1,)), nprocs=2, join=True)
+    for rank in range(2):
+        got = torch.load(f"{out}.{rank}")
+        assert got["error"] is not None and "disagree" in got["error"] and "[1]" in got["error"]
