@@ -749,6 +749,8 @@ def main():
     ap.add_argument("--burn-in", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fp32-network", action="store_true",
+                    help="skip the second timed run with exact fp32 weight-network products")
     ap.add_argument("--state-dim", type=int, default=None)
     ap.add_argument("--obs-dim", type=int, default=None)
     ap.add_argument("--bases", type=int, default=None)
@@ -875,7 +877,7 @@ def run_training(args, rank, world, dev, rehearsal):
         result["config"]["kalman_path_arithmetic"] = "fp32"
         if split:
             result["config"]["workload"] += "; weight network products bf16x3-split"
-        if split and world == 1 and T <= 100:
+        if split and world == 1 and T <= 100 and not args.no_fp32_network:
             _progress("timing the same step with exact fp32 weight-network products")
             lib.kvae_lstm128_set_precision(0)
             try:

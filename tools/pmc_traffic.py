@@ -5,6 +5,7 @@ half the bytes of wide coalesced reads).  usage: pmc_traffic.py counter_collecti
 import collections
 import csv
 import json
+import re
 import sys
 
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -13,7 +14,8 @@ for path in sys.argv[1:]:
         name = r["Kernel_Name"]
         if "kvae::" not in name:
             continue
-        short = name.split("kvae::")[1].split("(")[0]
+        # "void kvae::(anonymous namespace)::kernel<1, 2>(args...)" -> "kernel<1, 2>"
+        short = re.sub(r"\(anonymous namespace\)::", "", name.split("kvae::", 1)[1]).split("(")[0]
         vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
 out = {}
