@@ -714,36 +714,46 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             emit(T - 1, in, msr, Ps, z1c, z1r);
             in = nxt;
         }
-        for (int t = T - 2; t >= 0; --t) {
+        // Of an RTS step only D = Ps - Pn, (J D) J^T and the mean go through the recursion;
+        // Pn^-1 and the gain J = Pf An^T Pn^-1 of step t depend on the filter's results alone.
+        // They are formed one iteration ahead (`pre`), so that their long dependent chain (the
+        // inverse) interleaves with the Cholesky factor and the terms of the step before,
+        // and the gain's rows come back from LDS long before they are multiplied.
+        struct Pre {
+            V Pf, Pn, mr, mnc, J;
+        };
+        // wn: the weights of step t + 1 (they mix A_{t+1})
+        auto pre = [&](int t, const V* wn) {
+            Pre p;
+            p.Pf = env.ld_mat(env.at_mat(t, SL::M_PFILT));
+            p.Pn = env.ld_mat(env.at_mat(t, SL::M_PNEXT));
+            p.mr = env.ld_vec_r(env.at_vec(t, SL::V_M));
+            p.mnc = env.ld_vec_c(env.at_vec(t, SL::V_MN));
+            V hl;
+            const V Pi = spd_inverse<N>(p.Pn, hl, st, ST_NONPD_PREDICTED);
+            // what the adjoint reads again stays with its step, else in a scratch slot (two
+            // in turn: the rows of step t's gain are read while step t - 1's is written)
+            if (GRAD) env.st_mat(env.at_mat(t, SL::M_PINV), Pi);
+            // (operands that have just been computed go through lane rotations, not LDS)
+            const V W = mm4(mix_row<V, K>(wn, AKTs), rots(Pi));   // An^T Pn^-1
+            p.J = mm4(skew(p.Pf), rots(W));                        // Pf W
+            env.st_mat(GRAD ? env.at_mat(t, SL::M_J) : env.scr(1 + (t & 1)), p.J);
+            return p;
+        };
+        auto rts_step = [&](int t, const InS& in, const Pre& p) {
             const long tb = (long)t * B + b;
-            const InS nxt = load_S(clamp_t(t - 1));
-            // what the adjoint reads again stays with its step, else in a scratch slot
-            const auto locPi = GRAD ? env.at_mat(t, SL::M_PINV) : env.scr(1);
-            const auto locJ = GRAD ? env.at_mat(t, SL::M_J) : env.scr(2);
-            const auto locD = GRAD ? env.at_mat(t, SL::M_D) : env.scr(3);
+            const auto Jrows = env.ld_rows4(GRAD ? env.at_mat(t, SL::M_J) : env.scr(1 + (t & 1)));
             const V An = mix_row<V, K>(in.wn, AK), AnT = mix_row<V, K>(in.wn, AKT);
-            const V Pf = env.ld_mat(env.at_mat(t, SL::M_PFILT));
-            const V Pn = env.ld_mat(env.at_mat(t, SL::M_PNEXT));
-            const V mr = env.ld_vec_r(env.at_vec(t, SL::V_M));
-            const V mnc = env.ld_vec_c(env.at_vec(t, SL::V_MN));
-            const V dc = msc - mnc;
-            const V D = Ps - Pn;
+            const V dc = msc - p.mnc;
+            const V D = Ps - p.Pn;
             if (GRAD) {
-                env.st_mat(locD, D);
+                env.st_mat(env.at_mat(t, SL::M_D), D);
                 env.st_vec(env.at_vec(t, SL::V_D), dc);
             }
-            V hl;
-            const V Pi = spd_inverse<N>(Pn, hl, st, ST_NONPD_PREDICTED);
-            if (GRAD) env.st_mat(locPi, Pi);
-            // (operands that have just been computed go through lane rotations, not LDS: a
-            // round trip there would sit in the serial chain)
-            const V W = mm4(mix_row<V, K>(in.wn, AKTs), rots(Pi));   // An^T Pn^-1
-            const V J = mm4(skew(Pf), rots(W));               // Pf W
-            env.st_mat(locJ, J);
-            msr = mr + qsum(J * dc);
+            msr = p.mr + qsum(p.J * dc);
             msc = r2c(msr);
-            const V JD = mm4(skew(J), rots(D));               // J D
-            Ps = Pf + mm4(JD, env.ld_rows4(locJ));            // + (J D) J^T
+            const V JD = mm4(skew(p.J), rots(D));             // J D
+            Ps = p.Pf + mm4(JD, Jrows);                       // + (J D) J^T
             if (sym) Ps = symm(Ps);
             V zc, zr;
             emit(t, in, msr, Ps, zc, zr);
@@ -753,7 +763,19 @@ KR_FN void loss_row_sequence(Env& env, const LossBwdArgs<R>& g, long b, V* sums,
             if (t_trans) env.put_scalar(t_trans + tb + B, tr_);
             z1c = zc;
             z1r = zr;
-            in = nxt;
+        };
+        if (T >= 2) {
+            Pre cur = pre(T - 2, in.wn);
+            env.fence();
+            for (int t = T - 2; t >= 1; --t) {
+                const InS nxt = load_S(clamp_t(t - 1));
+                const Pre ahead = pre(t - 1, in.w);           // step t's weights mix A_t
+                rts_step(t, in, cur);
+                cur = ahead;
+                in = nxt;
+                env.fence();
+            }
+            rts_step(0, in, cur);
             env.fence();
         }
         // trans_0 = log N(z_0; m0, P0)

@@ -10,6 +10,8 @@ Each Function mirrors one piece of the reference:
 """
 import ctypes as C
 
+import math
+
 import torch
 
 from . import _capi as capi
@@ -563,9 +565,20 @@ class KalmanLossFunction(torch.autograd.Function):
         with_grad = any(need[:10])
         ctx.dims, ctx.weights = dims, (float(w_obs), float(w_trans), float(w_post))
         if with_grad:
-            grads = dict(d_a=new(T, B, p), d_alpha=new(T + 1, B, K), d_A_K=new(K, n, n),
-                         d_C_K=new(K, p, n), d_Q=new(n, n), d_R=new(p, p),
-                         d_m0=new(n) if need[7] else None, d_P0=new(n, n) if need[8] else None)
+            # all gradients in ONE buffer (each 256-byte aligned): the backward pass scales
+            # them by the cotangent with a single launch
+            shapes = dict(d_a=(T, B, p), d_alpha=(T + 1, B, K), d_A_K=(K, n, n), d_C_K=(K, p, n),
+                          d_Q=(n, n), d_R=(p, p), d_m0=(n,) if need[7] else None,
+                          d_P0=(n, n) if need[8] else None)
+            offsets, total = {}, 0
+            for name, shape in shapes.items():
+                if shape is not None:
+                    offsets[name] = total
+                    total += -(-math.prod(shape) // 64) * 64
+            flat = new(total)
+            grads = {name: None if shape is None else
+                     flat[offsets[name]:offsets[name] + math.prod(shape)].view(shape)
+                     for name, shape in shapes.items()}
             io = capi.LossBwd()
             capi.fill(io.fwd, a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q, R=R, m0=m0,
                       P0=P0, eps=eps, saved=saved, terms=terms, out=out,
@@ -577,7 +590,7 @@ class KalmanLossFunction(torch.autograd.Function):
             capi.check(lib.kvae_kalman_loss_value_and_grad(C.byref(dims), C.byref(io),
                                                            ws.data_ptr(), nbytes,
                                                            capi.current_stream_ptr()))
-            ctx.unit_grads = grads
+            ctx.unit_grads, ctx.unit_flat = grads, flat
         else:
             io = capi.fill(capi.LossFwd(), a=a, alpha=alpha, mask=mask, A_K=A_K, C_K=C_K, Q=Q,
                            R=R, m0=m0, P0=P0, eps=eps, saved=saved, terms=terms, out=out,
@@ -603,9 +616,8 @@ class KalmanLossFunction(torch.autograd.Function):
             # the usual case: only the objective was differentiated
             g = ctx.unit_grads
             ctx.unit_grads = None
-            names = ("d_a", "d_alpha", "d_A_K", "d_C_K", "d_Q", "d_R", "d_m0", "d_P0")
-            present = [g[k] for k in names if g[k] is not None]
-            torch._foreach_mul_(present, g_objective.reshape(()))
+            ctx.unit_flat.mul_(g_objective.reshape(()))      # (padding between them included)
+            ctx.unit_flat = None
             return (g["d_a"], g["d_alpha"], None, g["d_A_K"], g["d_C_K"], g["d_Q"], g["d_R"],
                     g["d_m0"], g["d_P0"], None, None, None, None, None, None, None)
         if g_weighted is None:

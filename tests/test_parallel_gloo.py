@@ -5,6 +5,7 @@ the flat-bucket all-reduce must reproduce the full-batch gradients."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -303,3 +304,54 @@ def test_ranks_that_disagree_on_a_gradient_are_told_so(tmp_path):
     for rank in range(2):
         got = torch.load(f"{out}.{rank}")
         assert got["error"] is not None and "disagree" in got["error"] and "[1]" in got["error"]
+
+
+def test_async_reduction_is_waited_for_only_before_the_bucket_is_refilled(monkeypatch):
+    """The order of an overlapped step: the all-reduce of step k is launched and NOT waited
+    for (the next replay of the training step runs beside it); the next all_reduce() call
+    waits for it before it packs step k+1's gradients into the same buffer; the flags of a
+    finished reduction are looked at, without blocking the launch path, one call later."""
+    import kalman_vae_amd.parallel as par
+    log = []
+
+    class Work:
+        def __init__(self, k):
+            self.k = k
+
+        def wait(self):
+            log.append(f"wait{self.k}")
+
+    count = {"k": 0}
+
+    def fake_all_reduce(tensor, op=None, group=None, async_op=False):
+        count["k"] += 1
+        log.append(f"launch{count['k']}")
+        assert async_op
+        return Work(count["k"])
+
+    monkeypatch.setattr(par.dist, "is_available", lambda: True)
+    monkeypatch.setattr(par.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(par.dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(par.dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(par.dist, "all_reduce", fake_all_reduce)
+    real_foreach = torch._foreach_copy_
+    monkeypatch.setattr(torch, "_foreach_copy_",
+                        lambda d, s, *a, **k: (log.append("pack"), real_foreach(d, s, *a, **k))[1])
+    w = torch.nn.Parameter(torch.ones(3))
+    bucket = par.FlatGradBucket([w])
+    for step in range(1, 4):
+        log.append(f"replay{step}")
+        w.grad = torch.full((3,), float(step))
+        handle = bucket.all_reduce(average=True, async_op=True)
+        assert isinstance(handle, Work) and torch.equal(w.grad, torch.full((3,), float(step)))
+    bucket.wait()
+    bucket.check()
+    assert log == ["replay1", "pack", "launch1",
+                   "replay2", "wait1", "pack", "launch2",
+                   "replay3", "wait2", "pack", "launch3", "wait3"]
+    # a flag that comes back as "one of two ranks" is reported at the next call
+    w.grad = torch.full((3,), 4.0)
+    bucket.all_reduce(average=True, async_op=True)
+    bucket.flags.fill_(0.5)
+    with pytest.raises(RuntimeError, match="disagree"):
+        bucket.all_reduce(average=True, async_op=True)
