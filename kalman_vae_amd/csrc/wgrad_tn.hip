@@ -54,7 +54,7 @@ __device__ __forceinline__ void wg_split8(const float (&x)[8], u32x4& hi, u32x4&
 }
 
 constexpr int WG_ROWS = 64;     // rows of a step
-constexpr int WG_LDC = 72;      // bf16 per LDS column (64 rows + 8: 144 bytes, columns 36 banks apart)
+constexpr int WG_PIECE = 8;     // bf16 of one 16-byte piece: 8 rows of one column
 constexpr int WG_GC = 512;      // columns of dG
 constexpr int WG_H = 128;       // columns of H
 constexpr int WG_AC = 128;      // columns of dG per workgroup
@@ -72,8 +72,22 @@ __global__ void __launch_bounds__(512)
 wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__ dG,
                 const float* __restrict__ Hm, float* __restrict__ partial,
                 long partial_stride) {
+    // A 64-row step of the combined tile as eight planes (one per 8-row group) of 256 16-byte
+    // pieces (one per column).  ds_read_b128 serves a wavefront in four groups of 16 lanes
+    // that are NOT contiguous ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32):
+    // a group holds all 16 values of lane & 15 but two values of lane >> 4, i.e. 16 adjacent
+    // columns of two planes.  A plane is a multiple of the 256-byte bank row, so the plane does
+    // not matter and 16 adjacent columns are conflict-free as long as their pieces fall into
+    // 16 different 16-byte slots of the row.  ds_write_b128 serves 8 contiguous lanes at a
+    // time, against a 128-byte row: a lane writes column 4 q + e, so 8 lanes are 32 columns
+    // apart in steps of 4.  `slot()` permutes the low four column bits (c2, c3, c0 ^ c4, c1)
+    // so that both hold.  (A column-major tile with 144-byte columns, conflict-free for
+    // contiguous 16-lane groups, measured 0.49 conflict cycles per LDS cycle.)
     struct Tile {
-        __bf16 hi[WG_TC * WG_LDC], lo[WG_TC * WG_LDC];
+        __bf16 hi[WG_ROWS / 8 * WG_TC * WG_PIECE], lo[WG_ROWS / 8 * WG_TC * WG_PIECE];
+    };
+    auto slot = [](int col) {
+        return (col & ~15) | ((col >> 2) & 3) | ((((col ^ (col >> 4)) & 1)) << 2) | ((col & 2) << 2);
     };
     __shared__ __attribute__((aligned(16))) Tile tl[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cc = lane & 15, s = lane >> 4;
@@ -105,9 +119,6 @@ wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__
             dst.v[jj] = (FULL || m < R) ? *reinterpret_cast<const f32x4v*>(src + m * stride) : z;
         }
     };
-    // a column's eight 8-row pieces are stored in the order g ^ ((column / 16) & 3): the
-    // 16-byte writes of a wavefront (columns 4 apart) then fall into different banks, and a
-    // matrix-instruction read (16 adjacent columns, one 16-column block) sees one order
     auto put_step = [&](int buf, const Stage& st) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -116,9 +127,9 @@ wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__
             for (int jj = 0; jj < 8; ++jj) x[jj] = st.v[jj][e];
             u32x4 hi, lo;
             wg_split8(x, hi, lo);
-            const int col = 4 * q + e, pg = g ^ ((col >> 4) & 3);
-            *reinterpret_cast<u32x4*>(&tl[buf].hi[col * WG_LDC + 8 * pg]) = hi;
-            *reinterpret_cast<u32x4*>(&tl[buf].lo[col * WG_LDC + 8 * pg]) = lo;
+            const int at = (g * WG_TC + slot(4 * q + e)) * WG_PIECE;
+            *reinterpret_cast<u32x4*>(&tl[buf].hi[at]) = hi;
+            *reinterpret_cast<u32x4*>(&tl[buf].lo[at]) = lo;
         }
     };
 
@@ -149,14 +160,14 @@ wgrad_tn_kernel(long R, long rows_per_slab, int slabs, const float* __restrict__
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int blk = 4 * wm + qq;
-            const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
+            const int off = ((4 * kh + s) * WG_TC + slot(16 * blk + cc)) * WG_PIECE;
             ah[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
             al[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int blk = WG_AC / 16 + 4 * wn + qq;
-            const int off = (16 * blk + cc) * WG_LDC + 8 * ((4 * kh + s) ^ (blk & 3));
+            const int off = ((4 * kh + s) * WG_TC + slot(16 * blk + cc)) * WG_PIECE;
             bh[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].hi[off]);
             bl[qq] = *reinterpret_cast<const bf16x8*>(&tl[buf].lo[off]);
         }

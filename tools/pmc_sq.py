@@ -11,9 +11,13 @@ for path in sys.argv[1:]:
         name = r["Kernel_Name"]
         if "kvae::" not in name:
             continue
-        short = name.split("kvae::")[1].split("(")[0]
-        if "loss_row_kernel" not in short:      # the row kernels differ by template arguments
-            short = short.split("<")[0]
+        import re
+        short = re.sub(r"\(anonymous namespace\)::", "", name.split("kvae::", 1)[1]).split("(")[0]
         vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, c in vals.items():
-    print(k, {n: sorted(v)[len(v) // 2] for n, v in c.items()})
+for k, c in sorted(vals.items()):
+    med = {n: sorted(v)[len(v) // 2] for n, v in c.items()}
+    waves = med.get("SQ_WAVES", 0.0)
+    print(f"{k}: {max(len(v) for v in c.values())} launches, {int(waves)} wavefronts")
+    for n, v in sorted(med.items()):
+        per = f"  per wavefront {v / waves:12.0f}" if waves else ""
+        print(f"   {n:34s} {v:16.0f}{per}")
