@@ -35,7 +35,9 @@ for i in range(cases):
     dtype = torch.float32 if (large or rng.random() < 0.6) else torch.float64
     T = rng.choice([1, 2, 3, 5, 8, 13, 20, 31])
     B = rng.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 130, 257]) if not large else rng.choice([1, 2, 5, 9])
-    os.environ["KVAE_SEQ_LANES"] = rng.choice(["1", "4"])
+    # 16: the fused objective with one sequence over 16 lanes (where it exists: float, n and p up
+    # to 4, T <= 35); the library takes the quad form for the other calls and shapes
+    os.environ["KVAE_SEQ_LANES"] = rng.choice(["1", "4", "16"])
     os.environ["KVAE_LARGE_STATE"] = rng.choice(["tile", "lds"])
     sym, burn = rng.random() < 0.7, rng.choice([0, 0, 1, 3])
     burn = min(burn, max(T - 1, 0))
@@ -45,9 +47,11 @@ for i in range(cases):
             f"large={os.environ['KVAE_LARGE_STATE']} sym={sym} burn_in={burn}")
     try:
         if kind == "filter":
-            KC.check_filter(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=1000 + i,
-                            mask_kind=rng.choice(["none", "binary", "fractional"]), symmetrize=sym,
-                            burn_in=burn, per_sequence_carry=rng.random() < 0.3)
+            filter_args = dict(T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=1000 + i,
+                               mask_kind=rng.choice(["none", "binary", "fractional"]),
+                               symmetrize=sym, burn_in=burn,
+                               per_sequence_carry=rng.random() < 0.3)
+            KC.check_filter(be, **filter_args)
         elif kind == "masked_mlp":
             KC.check_masked_mlp("cuda:0", T=T, B=B, n=n, p=p, K=K,
                                 hidden=rng.choice([1, 7, 32, 128, 200]), dtype=dtype, seed=4000 + i,
@@ -85,8 +89,9 @@ for i in range(cases):
                 assert e < tol, f"{k}: {e:.2e}"
             desc += f" (dims {no},{po},{Ko})"
         elif kind == "smooth":
-            KC.check_smooth(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=2000 + i,
-                            sample=rng.random() < 0.7, symmetrize=sym, burn_in=burn)
+            smooth_args = dict(T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=2000 + i,
+                               sample=rng.random() < 0.7, symmetrize=sym, burn_in=burn)
+            KC.check_smooth(be, **smooth_args)
         else:
             KC.check_elbo(be, T=T, B=B, n=n, p=p, K=K, dtype=dtype, seed=3000 + i)
     except Exception as err:  # noqa: BLE001
@@ -103,6 +108,10 @@ for i in range(cases):
                     KC.check_elbo(host, seed=3000 + i, **args)
                 elif kind == "loss":
                     KC.check_loss(host, **loss_args)
+                elif kind == "filter":
+                    KC.check_filter(host, **filter_args)
+                elif kind == "smooth":
+                    KC.check_smooth(host, **smooth_args)
             except Exception:  # noqa: BLE001
                 alike = True
         (conditioning if alike else failures).append(msg)
