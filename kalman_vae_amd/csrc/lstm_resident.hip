@@ -22,6 +22,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/kvae_kalman.h"
 #include "lstm_common.h"
@@ -569,34 +570,64 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
         wh[k][1] = head.W[k * RH + ub + 1];
         hw[k][0] = hw[k][1] = 0.f;
     }
-    auto load_rows = [&](int t, CellRows<KH>& in) {
+    // first: the step the sweep starts with (t = T-1), the only one that reads its own c_t
+    // (std::true_type / std::false_type).  FULL: every access is unconditional and the address
+    // of c_{t-1} is chosen by scalar selects (the step below's c; c_init at t = 0; any valid
+    // address times zero without one), so the time loop below has no branch and the compiler
+    // counts the outstanding memory operations exactly -- with branches it waits for ALL of
+    // them, the step's 16 stores of gate gradients included, before it touches the next step's
+    // inputs.
+    auto load_rows = [&](int t, auto first, CellRows<KH>& in) {
         const float2 z = {0.f, 0.f};
+        constexpr bool FIRST = decltype(first)::value;
+        const float* cp_base = t > 0 ? cg + (long)(t - 1) * BH : (c_init ? c_init : cg);
+        const float cp_scale = (t > 0 || c_init) ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 4 * s + i;
             const float2 c_here = in.cp[i];
-            in.ig[i] = in.fg[i] = in.gg[i] = in.og[i] = in.cp[i] = in.gh[i] = z;
-            in.cc[i] = t == T - 1 ? z : c_here;
-            if (FULL || row < B) {
+            const long o = (long)row * RH + ub;
+            if constexpr (FULL) {
                 const float* gr = gates + t * BG + (long)row * RG4 + ub;
                 in.ig[i] = load_streaming(gr);
                 in.fg[i] = load_streaming(gr + RH);
                 in.gg[i] = load_streaming(gr + 2 * RH);
                 in.og[i] = load_streaming(gr + 3 * RH);
-                const long o = (long)row * RH + ub;
-                if (t == T - 1) in.cc[i] = load_streaming(cg + t * BH + o);
-                if (t > 0) {
-                    in.cp[i] = load_streaming(cg + (t - 1) * BH + o);
-                } else if (c_init) {
-                    in.cp[i] = *reinterpret_cast<const float2*>(c_init + o);
+                in.cc[i] = FIRST ? load_streaming(cg + t * BH + o) : c_here;
+                const float2 cp = load_streaming(cp_base + o);
+                in.cp[i] = make_float2(cp.x * cp_scale, cp.y * cp_scale);
+                in.gh[i] = KH == 0 ? load_streaming(g_h + t * BH + o) : z;
+                if (KH > 0) {
+                    // (lanes whose k is not a logit read logit 0 and drop it)
+                    const int k = cc & 3, kq = k < KH ? k : 0;
+                    const float al = head.alpha[((long)t * B + row) * KH + kq];
+                    const float ga = head.g_alpha[((long)t * B + row) * KH + kq];
+                    in.al[i] = k < KH ? al : 0.f;
+                    in.ga[i] = k < KH ? ga : 0.f;
                 }
-                if (KH == 0) in.gh[i] = load_streaming(g_h + t * BH + o);
-            }
-            if (KH > 0) {
-                const int k = cc & 3;
-                const bool ok = (FULL || row < B) && k < KH;
-                in.al[i] = ok ? head.alpha[((long)t * B + row) * KH + k] : 0.f;
-                in.ga[i] = ok ? head.g_alpha[((long)t * B + row) * KH + k] : 0.f;
+            } else {
+                in.ig[i] = in.fg[i] = in.gg[i] = in.og[i] = in.cp[i] = in.gh[i] = z;
+                in.cc[i] = FIRST ? z : c_here;
+                if (row < B) {
+                    const float* gr = gates + t * BG + (long)row * RG4 + ub;
+                    in.ig[i] = load_streaming(gr);
+                    in.fg[i] = load_streaming(gr + RH);
+                    in.gg[i] = load_streaming(gr + 2 * RH);
+                    in.og[i] = load_streaming(gr + 3 * RH);
+                    if (FIRST) in.cc[i] = load_streaming(cg + t * BH + o);
+                    if (t > 0) {
+                        in.cp[i] = load_streaming(cg + (t - 1) * BH + o);
+                    } else if (c_init) {
+                        in.cp[i] = *reinterpret_cast<const float2*>(c_init + o);
+                    }
+                    if (KH == 0) in.gh[i] = load_streaming(g_h + t * BH + o);
+                }
+                if (KH > 0) {
+                    const int k = cc & 3;
+                    const bool ok = row < B && k < KH;
+                    in.al[i] = ok ? head.alpha[((long)t * B + row) * KH + k] : 0.f;
+                    in.ga[i] = ok ? head.g_alpha[((long)t * B + row) * KH + k] : 0.f;
+                }
             }
         }
     };
@@ -604,8 +635,10 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     CellRows<KH> in;
 #pragma unroll
     for (int i = 0; i < 4; ++i) in.cp[i] = make_float2(0.f, 0.f);
-    load_rows(T - 1, in);
-    for (int t = T - 1; t >= 0; --t) {
+    load_rows(T - 1, std::true_type{}, in);
+    // one step; more: whether steps below it follow (a bool, or std::true_type /
+    // std::false_type where the caller knows: then nothing in the step branches on it)
+    auto step = [&](int t, auto more) {
 #ifndef KVAE_LSTM_BF16X3
         float* g_tile = tile[t & 1];
 #endif
@@ -716,7 +749,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             }
         }
         // inputs of the next step, in flight during the matrix instructions below
-        if (t > 0) load_rows(t - 1, in);
+        if (more) load_rows(t - 1, std::false_type{}, in);
         lds_barrier();
         if (P > 0 && threadIdx.x < 16 * P) {
             const int lr = threadIdx.x / (P > 0 ? P : 1), q = threadIdx.x % (P > 0 ? P : 1);
@@ -737,7 +770,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             if (FULL || r0 + 4 * s + i < B) store_streaming(dG + t * BG + (long)(r0 + 4 * s + i) * RG4 + g * RH + ub, dgs[i][g]);
         };
 #ifdef KVAE_LSTM_BF16X3
-        if (t > 0) {
+        if (more) {
             // A operands: row cc of the gate-gradient tile, elements 32 kk + 8 s .. + 7; read
             // AG k-groups ahead of the matrix instructions that use them (one with the softmax
             // head's accumulators in the kernel, which needs the registers)
@@ -770,7 +803,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
             }
         } else {
 #else
-        if (t > 0) {
+        if (more) {
             const float* a_row = g_tile + cc * RLDG + s;
 #pragma unroll
             for (int kb = 0; kb < 128; ++kb) {
@@ -789,6 +822,12 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
         }
         // tile[t & 1] is rewritten in step t-2, after the barrier of step t-1 that every
         // wavefront reaches only after its reads above
+    };
+    if constexpr (FULL) {
+        for (int t = T - 1; t >= 1; --t) step(t, std::true_type{});
+        step(0, std::false_type{});
+    } else {
+        for (int t = T - 1; t >= 0; --t) step(t, t > 0);
     }
     if (KH > 0) {
         // every lane of the workgroup that owns row group s saw the same dl: the weight sums
@@ -836,7 +875,7 @@ lstm128_backward_body(int T, int B, const float* __restrict__ x, const float* __
     }
 }
 
-template <int P, int KH>
+template <int P, int KH, bool FULL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 KVAE_BWD_KERNEL(int T, int B, const float* __restrict__ x,
                                  const float* __restrict__ Wih, const float* __restrict__ gates,
@@ -850,9 +889,9 @@ KVAE_BWD_KERNEL(int T, int B, const float* __restrict__ x,
     __shared__ __attribute__((aligned(16))) float tile[2][16 * RLDG];
 #endif
     __shared__ float dx_part[2][4][16][P > 0 ? P : 1];
-    // (one body for full and ragged tiles: a second, unpredicated instance costs registers
-    // the resident matrix needs)
-    lstm128_backward_body<P, false, KH>(T, B, x, Wih, gates, cg, c_init, g_h, Whh, dG, dx,
+    // (full and ragged tiles are separate kernels: an unpredicated path beside the predicated
+    // one in the same kernel costs registers the resident matrix needs)
+    lstm128_backward_body<P, FULL, KH>(T, B, x, Wih, gates, cg, c_init, g_h, Whh, dG, dx,
                                         partial, head, tile, dx_part);
 }
 
@@ -883,13 +922,17 @@ int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const
                     hipStream_t stream) {
     const dim3 grid((B + 15) / 16);
     const HeadAdjoint head = {alpha, g_alpha, Wh, head_partial};
+    const bool full = B % 16 == 0;
     if (KH > 0) {
         // the head sits on the upper layer, whose input projection is never formed in the kernel
         if (P != 0) return KVAE_E_UNSUPPORTED;
-#define KVAE_R128H(K_)                                                                       \
-    case K_:                                                                                 \
-        hipLaunchKernelGGL((KVAE_BWD_KERNEL<0, K_>), grid, dim3(256), 0, stream, T, B, x, Wih, \
-                           gates, c, c_init, g_h, Whh, dG, dx, partial, head);               \
+        // (with the head's accumulators in the kernel the branch-free instance is slower, 138
+        // against 103 us at T = 20, B = 4096: its gate gradients are stored before the next
+        // step's inputs are requested, so exact counts of outstanding operations gain nothing)
+#define KVAE_R128H(K_)                                                                        \
+    case K_:                                                                                  \
+        hipLaunchKernelGGL((KVAE_BWD_KERNEL<0, K_, false>), grid, dim3(256), 0, stream, T, B, \
+                           x, Wih, gates, c, c_init, g_h, Whh, dG, dx, partial, head);        \
         break;
         switch (KH) {
             KVAE_R128H(2) KVAE_R128H(3) KVAE_R128H(4)
@@ -898,9 +941,15 @@ int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const
 #undef KVAE_R128H
         return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
     }
-#define KVAE_R128B(P_)                                                                    \
-    hipLaunchKernelGGL((KVAE_BWD_KERNEL<P_, 0>), grid, dim3(256), 0, stream, T, B, x, Wih, gates, \
-                       c, c_init, g_h, Whh, dG, dx, partial, head)
+#define KVAE_R128B(P_)                                                                         \
+    do {                                                                                       \
+        if (full)                                                                              \
+            hipLaunchKernelGGL((KVAE_BWD_KERNEL<P_, 0, true>), grid, dim3(256), 0, stream, T, B, \
+                               x, Wih, gates, c, c_init, g_h, Whh, dG, dx, partial, head);     \
+        else                                                                                   \
+            hipLaunchKernelGGL((KVAE_BWD_KERNEL<P_, 0, false>), grid, dim3(256), 0, stream, T, B, \
+                               x, Wih, gates, c, c_init, g_h, Whh, dG, dx, partial, head);     \
+    } while (0)
     switch (P) {
         case 0: KVAE_R128B(0); break;
         case 1: KVAE_R128B(1); break;
