@@ -848,6 +848,7 @@ def run_training(args, rank, world, dev, rehearsal):
         elapsed = _timed_steps(step, args, world, dev, rehearsal)
         if bucket is not None:
             bucket.wait()
+            bucket.check()
     if rank != 0:
         return None
     units = T * B

@@ -41,9 +41,10 @@ class FlatGradBucket:
     gradient for a parameter would keep ``grad = None`` while the others step on it, and the
     replicas would drift apart.  One flag per parameter rides at the end of the buffer
     through the same all-reduce; a flag that comes back neither 0 nor "all ranks" raises
-    ``RuntimeError`` -- at once for a blocking reduction, at the next ``wait()`` /
-    ``all_reduce()`` / ``check()`` for an asynchronous one (its flags are copied to the host
-    without blocking).
+    ``RuntimeError`` -- at once for a blocking reduction; for an asynchronous one its flags
+    are copied to the host without blocking when it is waited for and looked at one
+    ``all_reduce()`` later (or by ``check()``), so that the host never stalls on the reduction
+    it overlaps.
 
     ``async_op=True`` returns the collective's work handle: the reduction runs
     on the backend's own stream, and the caller waits on the handle before reading the
@@ -69,35 +70,39 @@ class FlatGradBucket:
         self._flags_stale = True        # the buffer's flags are not this rank's pattern
         self._clean = [True] * len(self.params)   # slice known to be all zero
         self._host_flags = None
-        self._unchecked = None          # (event or None, pattern, scale, world) of a reduction
+        self._inflight = None           # (pattern, scale, world) of the reduction in flight
+        self._copied = None             # (event, pattern, scale, world): its flags, on their way
 
     def wait(self):
-        """Block the current stream until the last asynchronous all-reduce is done."""
-        if self._pending is not None:
-            self._pending.wait()
-            self._pending = None
-            if self._unchecked is not None and self._unchecked[0] is None:
-                # flags to the host behind the reduction, without blocking; looked at later
-                if self._host_flags is None:
-                    self._host_flags = torch.empty(len(self.params), dtype=self.flags.dtype,
-                                                   pin_memory=self.flags.is_cuda)
-                self._host_flags.copy_(self.flags, non_blocking=True)
-                event = None
-                if self.flags.is_cuda:
-                    event = torch.cuda.Event()
-                    event.record()
-                self._unchecked = (event or True,) + self._unchecked[1:]
-                return
-        self.check()
+        """Block the current stream until the last asynchronous all-reduce is done.  Its flags
+        are copied to the host behind it without blocking; they are looked at by the wait()
+        after this one, by which time the copy finished a step ago (looking at them at once
+        would stall the host on the reduction it is meant to overlap), or by check()."""
+        if self._pending is None:
+            return
+        self._pending.wait()
+        self._pending = None
+        self.check()                      # the reduction before this one
+        if self._inflight is not None:
+            if self._host_flags is None:
+                self._host_flags = torch.empty(len(self.params), dtype=self.flags.dtype,
+                                               pin_memory=self.flags.is_cuda)
+            self._host_flags.copy_(self.flags, non_blocking=True)
+            event = None
+            if self.flags.is_cuda:
+                event = torch.cuda.Event()
+                event.record()
+            self._copied = (event,) + self._inflight
+            self._inflight = None
 
     def check(self):
-        """Raise if the ranks of the last finished reduction disagreed on which parameters
-        received a gradient."""
-        if self._unchecked is None or self._unchecked[0] is None:
+        """Raise if the ranks of the last reduction that wait() has been called for disagreed
+        on which parameters received a gradient (blocks until its flags are on the host)."""
+        if self._copied is None:
             return
-        event, pattern, scale, world = self._unchecked
-        self._unchecked = None
-        if event is not True:
+        event, pattern, scale, world = self._copied
+        self._copied = None
+        if event is not None:
             event.synchronize()
         self._verify(self._host_flags.tolist(), pattern, scale, world)
 
@@ -150,7 +155,6 @@ class FlatGradBucket:
     def all_reduce(self, average=True, group=None, async_op=False):
         """Sum (or average) the gradients over all ranks, in place in the flat buffer."""
         self.wait()
-        self.check()
         self.pack()
         work = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -179,7 +183,7 @@ class FlatGradBucket:
             if blocking:
                 self._verify(self.flags.tolist(), self._pattern, scale, world)
             else:
-                self._unchecked = (None, self._pattern, scale, world)
+                self._inflight = (self._pattern, scale, world)
         self.bind()
         if async_op and work is not None:
             self._pending = work

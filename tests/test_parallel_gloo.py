@@ -349,9 +349,15 @@ def test_async_reduction_is_waited_for_only_before_the_bucket_is_refilled(monkey
     assert log == ["replay1", "pack", "launch1",
                    "replay2", "wait1", "pack", "launch2",
                    "replay3", "wait2", "pack", "launch3", "wait3"]
-    # a flag that comes back as "one of two ranks" is reported at the next call
+    # a flag that comes back as "one of two ranks": copied to the host when the reduction is
+    # waited for, reported by check() or by the wait after that
     w.grad = torch.full((3,), 4.0)
     bucket.all_reduce(average=True, async_op=True)
     bucket.flags.fill_(0.5)
+    bucket.all_reduce(average=True, async_op=True)        # waits for the poisoned one
+    with pytest.raises(RuntimeError, match="disagree"):
+        bucket.check()
+    bucket.flags.fill_(0.5)
+    bucket.all_reduce(average=True, async_op=True)
     with pytest.raises(RuntimeError, match="disagree"):
         bucket.all_reduce(average=True, async_op=True)
