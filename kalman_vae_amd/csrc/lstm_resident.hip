@@ -926,9 +926,9 @@ int KVAE_LAUNCH_BWD(int T, int B, int P, const float* x, const float* Wih, const
     if (KH > 0) {
         // the head sits on the upper layer, whose input projection is never formed in the kernel
         if (P != 0) return KVAE_E_UNSUPPORTED;
-        // (with the head's accumulators in the kernel the branch-free instance is slower, 138
-        // against 103 us at T = 20, B = 4096: its gate gradients are stored before the next
-        // step's inputs are requested, so exact counts of outstanding operations gain nothing)
+        // (with the head's accumulators in the kernel the branch-free instance measured slower,
+        // 138 against 103 us at T = 20, B = 4096, with immediate and with deferred stores of the
+        // gate gradients alike: these kernels keep the predicated form)
 #define KVAE_R128H(K_)                                                                        \
     case K_:                                                                                  \
         hipLaunchKernelGGL((KVAE_BWD_KERNEL<0, K_, false>), grid, dim3(256), 0, stream, T, B, \
