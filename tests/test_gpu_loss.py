@@ -45,6 +45,8 @@ def test_loss_matches_oracle(be, n, p, K, dtype, mask_kind):
 def test_loss_options(be, symmetrize, burn_in, stride):
     KC.check_loss(be, T=7, B=130, n=4, p=2, K=3, dtype=torch.float64, seed=13,
                   mask_kind="binary", symmetrize=symmetrize, burn_in=burn_in, stride=stride)
+    KC.check_loss(be, T=7, B=130, n=4, p=2, K=3, dtype=torch.float32, seed=13,
+                  mask_kind="binary", symmetrize=symmetrize, burn_in=burn_in, stride=stride)
 
 
 @pytest.mark.parametrize("B", [1, 16, 63, 64, 65, 1000])
@@ -55,6 +57,11 @@ def test_loss_ragged_batches(be, B):
 def test_loss_short_sequences(be):
     KC.check_loss(be, T=1, B=5, n=4, p=2, K=3, dtype=torch.float64, seed=6)
     KC.check_loss(be, T=2, B=5, n=4, p=2, K=3, dtype=torch.float64, seed=7, burn_in=1)
+    # float32 as well: the 16-lane form exists for float only, and its peeled first and last
+    # steps are all there is at T = 1, 2 and 3
+    for T in (1, 2, 3):
+        KC.check_loss(be, T=T, B=7, n=4, p=2, K=3, dtype=torch.float32, seed=40 + T,
+                      mask_kind="binary" if T > 1 else "none")
 
 
 @pytest.mark.parametrize("n,p,K", [(4, 2, 3), (2, 1, 2), (3, 2, 2), (4, 2, 8)])
