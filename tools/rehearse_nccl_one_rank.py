@@ -35,7 +35,31 @@ for i in range(5):
     for (k, p), x in zip(named, before):
         assert torch.equal(x, p.grad), (k, tuple(p.shape), int(torch.isnan(x).sum()),
                                         int(torch.isnan(p.grad).sum()), float((x - p.grad).abs().max()))
+# The bucket skips the collective at world size 1.  Tell it the world has two ranks (the group
+# still has one, so RCCL's AVG / SUM over it is the identity): the real RCCL call on the flat
+# buffer with its agreement flags, blocking and overlapped, the work handle's wait(), the
+# non-blocking copy of the flags to pinned memory and their check one call later all execute.
+import kalman_vae_amd.parallel as par
+real_world = par.dist.get_world_size
+par.dist.get_world_size = lambda group=None: 2
+try:
+    for overlapped in (False, True):
+        for i in range(4):
+            obj = step(None)
+            before = [p.grad.clone() for _, p in named]
+            # (a sum over "two" ranks is what one rank's flags look like to the check as half
+            # of the expected count: only the average is consistent with a group of one)
+            out = bucket.all_reduce(average=True, async_op=overlapped)
+            if overlapped:
+                assert hasattr(out, "wait")
+        bucket.wait()
+        bucket.check()
+        for (k, p), x in zip(named, before):
+            assert torch.equal(x, p.grad), k
+finally:
+    par.dist.get_world_size = real_world
 dist.barrier()
 torch.cuda.synchronize()
-print("objective", float(obj), "ok: graph replay + RCCL all-reduce, 5 steps")
+print("objective", float(obj), "ok: graph replay + RCCL all-reduce, 5 steps; the bucket's collective path "
+      "(blocking and overlapped) with its flags on a one-rank group")
 dist.destroy_process_group()
