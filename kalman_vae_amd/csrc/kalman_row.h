@@ -297,20 +297,22 @@ KR_FN float guard_pivot(float x, int& st, int bit) {
     return ok ? x : 1.f;
 }
 // The product core.  The compiler does not fold a DPP exchange into a multiply-add (it forms
-// v_fmac_f32 only after its DPP pass has run) and spends a move per term, so the four
+// v_fmac_f32 only after its DPP pass has run) and spends a move per term, so three of the four
 // instructions are written out.  A DPP operand must have been written at least two wait
-// states earlier and the compiler cannot see that this statement reads X that way, nor that
-// the next statement may read the result that way: hence the s_nop on either side.
+// states earlier.  The compiler keeps that distance for instructions it can see: it sees the
+// first term (a multiply, into which it does fold the exchange), so X is old enough when the
+// asm reads it the same way, and it treats the asm's result like any other definition when a
+// later DPP instruction reads it.  No fixed padding is needed (with an s_nop on either side
+// of a four-instruction asm block the kernel took 73.2 instead of 72.0 us).
 KR_FN float mm4(float X, const Q4<float>& y) {
-    float acc;
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1"
-        : "=&v"(acc)
-        : "v"(X), "v"(y.v[0]), "v"(y.v[1]), "v"(y.v[2]), "v"(y.v[3]));
+    // the first term is the compiler's (it folds the exchange into a multiply and keeps X's
+    // two wait states itself); the asm's later reads of X are then late enough by themselves
+    float acc = qb<0>(X) * y.v[0];
+    asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(acc)
+        : "v"(X), "v"(y.v[1]), "v"(y.v[2]), "v"(y.v[3]));
     return acc;
 }
 #endif  // __HIPCC__
