@@ -19,9 +19,8 @@ How the work is split:
     consumes the generator identically (``rng_parity``; switch it off to draw
     one tensor per call instead of two per step).
 """
-from typing import Optional
-
 import contextlib
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -86,7 +85,7 @@ class StateSpaceModel(nn.Module):
         # behaviour switches that have no counterpart in the reference
         self._matrix_cache = None   # see cached_matrices()
         self._noise_pool = None     # see _draw()
-        self._draw_log = None       # see _log_draws()
+        self._draw_log = None       # see _recording_draws()
         self._defer_status = False  # kalman_elbo reads the status word once per step
         self.rng_parity = True      # draw noise exactly like the reference does
         # kalman_elbo: compute the objective with the one-launch-per-direction kernels that
@@ -211,20 +210,21 @@ class StateSpaceModel(nn.Module):
             self._draw_log.append(eps)
         return eps
 
-    def _log_draws(self):
-        """Start recording what _draw hands out (a fused path draws all its noise before it
-        learns whether a kernel covers the call)."""
-        self._draw_log = []
-        return self._draw_log
-
-    def _keep_draws(self):
-        self._draw_log = None
+    @contextlib.contextmanager
+    def _recording_draws(self):
+        """Record what _draw hands out inside the block (a fused path draws all its noise
+        before it learns whether a kernel covers the call); the record is the block's value.
+        Recording stops when the block ends, however it ends."""
+        log = self._draw_log = []
+        try:
+            yield log
+        finally:
+            self._draw_log = None
 
     def _undo_draws(self, log):
         """The path that drew `log` did not run: queue its tensors, in order, for the path that
         runs instead.  Both draw the same shapes in the same order (the reference's), so the
         generator is consumed once and the results are those of the reference's draw order."""
-        self._draw_log = None
         if log:
             self._noise_pool = list(log) + list(self._noise_pool or [])
 
@@ -303,14 +303,13 @@ class StateSpaceModel(nn.Module):
                 and F.masked_mlp_grad_supported(layers[0].out_features, self.z_dim, self.a_dim,
                                                 self.K, as_.dtype)):
             # two-layer perceptron under autograd: one launch per direction
-            log = self._log_draws()
-            out = F.masked_filter_mlp_grad(
-                as_, mask, layers[0], layers[1], A_K, C_K, Q, R, self.initial_state_mean,
-                self.initial_state_covariance, *self._filter_draws_split(as_, state_noise,
-                                                                          obs_noise, L_Q, L_R),
-                symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
+            with self._recording_draws() as log:
+                out = F.masked_filter_mlp_grad(
+                    as_, mask, layers[0], layers[1], A_K, C_K, Q, R, self.initial_state_mean,
+                    self.initial_state_covariance,
+                    *self._filter_draws_split(as_, state_noise, obs_noise, L_Q, L_R),
+                    symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
             if out is not None:
-                self._keep_draws()
                 return out[:7] + (out[7][:T],)
             self._undo_draws(log)
         if (not torch.is_grad_enabled() and as_.is_cuda
@@ -319,18 +318,16 @@ class StateSpaceModel(nn.Module):
             if (layers is not None and len(layers) == 2 and self.in_kernel_weight_network
                     and F.masked_mlp_fits(layers[0].out_features, self.a_dim, self.K, as_.dtype)):
                 # two-layer perceptron: the network runs inside the filter kernel
-                log = self._log_draws()
-                fast = self._filter_masked_mlp(as_, mask, state_noise, obs_noise, symmetrize,
-                                               L_Q, L_R, layers)
+                with self._recording_draws() as log:
+                    fast = self._filter_masked_mlp(as_, mask, state_noise, obs_noise, symmetrize,
+                                                   L_Q, L_R, layers)
                 if fast is not None:
-                    self._keep_draws()
                     return fast
                 self._undo_draws(log)
-            log = self._log_draws()
-            fast = self._filter_masked_inference(as_, mask, state_noise, obs_noise, symmetrize,
-                                                 w, m_pred, P_pred, L_Q, L_R)
+            with self._recording_draws() as log:
+                fast = self._filter_masked_inference(as_, mask, state_noise, obs_noise,
+                                                     symmetrize, w, m_pred, P_pred, L_Q, L_R)
             if fast is not None:
-                self._keep_draws()
                 return fast
             self._undo_draws(log)
         A_t = mix(w, A_K)
@@ -510,8 +507,7 @@ class StateSpaceModel(nn.Module):
         if (as_.is_cuda and (mask is None or in_kernel)
                 and F.rollout_supported(self.z_dim, self.a_dim, self.K, as_.dtype)):
             self.weight_model.clear_hidden_state()
-            log = self._log_draws()
-            with self.cached_matrices():
+            with self._recording_draws() as log, self.cached_matrices():
                 common = (self.mat_A_K, self.mat_C_K, self.mat_Q, self.mat_R,
                           self.initial_state_mean, self.initial_state_covariance)
                 if mask is None:
@@ -538,7 +534,6 @@ class StateSpaceModel(nn.Module):
                         want=("a_w", "as_resampled"))
                     filter_as = out["a_w"] if out is not None else None
             if out is not None:
-                self._keep_draws()
                 self._finish(as_.device)
                 return filter_as, out["as_resampled"]
             # no kernel for this call after all: the two calls below are served the noise

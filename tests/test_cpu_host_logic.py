@@ -280,9 +280,9 @@ def test_undone_draws_are_served_again_in_order():
     ssm = StateSpaceModel(2, 4, 3, "mlp", hidden_dim=8)
     like = torch.zeros(1)
     torch.manual_seed(3)
-    log = ssm._log_draws()
-    first = [ssm._draw((5, 4), like), ssm._draw((5, 2), like), ssm._draw((5, 4), like)]
-    assert len(log) == 3
+    with ssm._recording_draws() as log:
+        first = [ssm._draw((5, 4), like), ssm._draw((5, 2), like), ssm._draw((5, 4), like)]
+    assert len(log) == 3 and ssm._draw_log is None
     ssm._undo_draws(log)
     again = [ssm._draw((5, 4), like), ssm._draw((5, 2), like), ssm._draw((5, 4), like)]
     assert all(x is y for x, y in zip(first, again)) and not ssm._noise_pool
@@ -293,8 +293,14 @@ def test_undone_draws_are_served_again_in_order():
         assert torch.equal(x, y)
     # a queue that was installed before (all the noise of a step, drawn at once) stays behind
     ssm._noise_pool = [torch.ones(2, 2)]
-    log = ssm._log_draws()
-    ssm._draw((2, 2), like)
+    with ssm._recording_draws() as log:
+        ssm._draw((2, 2), like)
     ssm._noise_pool = [torch.zeros(1, 1)]
+    try:                                     # recording stops when the block fails, too
+        with ssm._recording_draws():
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert ssm._draw_log is None
     ssm._undo_draws(log)
     assert [tuple(t.shape) for t in ssm._noise_pool] == [(2, 2), (1, 1)]
