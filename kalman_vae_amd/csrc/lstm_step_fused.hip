@@ -37,10 +37,23 @@
 #include "../../include/kvae_kalman.h"
 #include "lstm_common.h"
 
-// 1: pin the lower layer's weights to accumulation registers too.  Miscompiled (see the pin
-// below); exists to rebuild the failing form for tools/exp/orphan_spills.py.
+// This file is compiled three times: as it is (the lower layer's one-input instances and the C
+// entry point), with KVAE_SF_UPPER (the upper layer's instances) and with KVAE_SF_LOWER2 (the
+// lower layer's two-input instances); the last two keep their weights pinned to accumulation
+// registers and are built with the option that keeps matrix-instruction results in ordinary
+// registers.  Those two are assembled from the compiler's listing after one wait state has been
+// put between every packed vector instruction and a directly following matrix instruction: one
+// such pair in the two-input instance lost part of the packed instruction's write
+// (tools/exp/packed_before_mfma.py; the Makefile has the steps).
+// KVAE_SF_PIN_LOWER = 1 pins the weights of whatever lower-layer instance a build holds.  In the
+// default build that is miscompiled (see the pin below); the setting exists to rebuild the
+// failing form for tools/exp/orphan_spills.py.
 #ifndef KVAE_SF_PIN_LOWER
+#ifdef KVAE_SF_LOWER2
+#define KVAE_SF_PIN_LOWER 1
+#else
 #define KVAE_SF_PIN_LOWER 0
+#endif
 #endif
 
 namespace kvae {
@@ -117,16 +130,20 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
                 // the matrix instruction reads its B operand from accumulation registers as
                 // well: keep the upper layer's weights there, so that the 256 ordinary
                 // registers hold the tiles in flight without copies between the two files
-                // (484 -> 406 instructions per tile).  Not for the lower layer: its 64 weight
-                // vectors fill all 256 accumulation registers, the accumulators want 32 of
-                // them as well, and the allocator evicts pinned vectors.  It saves the pieces
+                // (484 -> 406 instructions per tile; the lower layer's two-input instance 693 ->
+                // 455).  The pin is safe only while the allocator never evicts a pinned vector:
+                // with the accumulators in accumulation registers too (the default build) the
+                // lower layer's 64 weight vectors fill that file, the accumulators want 32 of
+                // its registers, and the allocator evicts pinned vectors.  It saves the pieces
                 // of an evicted 128-bit vector in different places (two dwords to scratch, two
                 // to spare registers) and restores only three of the four before the matrix
                 // instruction that reads the vector: the fourth operand register keeps its
                 // stale content, and the product is right or wrong with that content.
                 // tools/exp/orphan_spills.py finds the unrestored piece in the listing
-                // (-DKVAE_SF_PIN_LOWER=1 builds that form); the Makefile refuses an upper-layer
-                // object with any spill in it.
+                // (-DKVAE_SF_PIN_LOWER=1 builds that form).  The builds that pin keep their
+                // accumulators in ordinary registers and the Makefile refuses their objects if
+                // the listing has any spill; the one-input instance spills even so and stays
+                // unpinned.
                 if constexpr (P == 0 || KVAE_SF_PIN_LOWER)
                     asm volatile("" : "+a"(whi[ub][g][kk]), "+a"(wlo[ub][g][kk]));
             }
@@ -356,6 +373,10 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
 int launch_lstm128_step_upper(long B, const float* x, const float* Wx, const float* h_prev,
                               const float* c_prev, const float* WhhT, const float* bias,
                               float* h_out, float* c_out, int cus, hipStream_t s);
+// The lower layer's two-input instances, likewise (KVAE_SF_LOWER2).
+int launch_lstm128_step_lower2(long B, const float* x, const float* Wx, const float* h_prev,
+                               const float* c_prev, const float* WhhT, const float* bias,
+                               float* h_out, float* c_out, int cus, hipStream_t s);
 
 #define KVAE_SF_ARGS B, x, Wx, h_prev, c_prev, WhhT, bias, h_out, c_out
 #define KVAE_SF_LAUNCH(P_, grid_)                                                             \
@@ -388,9 +409,21 @@ int launch_lstm128_step_upper(long B, const float* x, const float* Wx, const flo
 }
 #endif
 
+#ifdef KVAE_SF_LOWER2
+int launch_lstm128_step_lower2(long B, const float* x, const float* Wx, const float* h_prev,
+                               const float* c_prev, const float* WhhT, const float* bias,
+                               float* h_out, float* c_out, int cus, hipStream_t s) {
+    const bool full = B % 16 == 0, state = h_prev != nullptr;
+    const long tiles = (B + 15) / 16;
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    KVAE_SF_LAUNCH(2, grid);
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+#endif
+
 }  // namespace kvae
 
-#ifndef KVAE_SF_UPPER
+#if !defined(KVAE_SF_UPPER) && !defined(KVAE_SF_LOWER2)
 using namespace kvae;
 
 extern "C" {
@@ -416,10 +449,9 @@ int kvae_lstm128_step_fused(long B, int P, const void* x_, const void* Wx_, cons
     const bool full = B % 16 == 0, state = h_prev != nullptr;
     const long tiles = (B + 15) / 16;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
-    if (P == 1)
-        KVAE_SF_LAUNCH(1, grid);
-    else
-        KVAE_SF_LAUNCH(2, grid);
+    if (P == 2)
+        return launch_lstm128_step_lower2(B, x, Wx, h_prev, c_prev, WhhT, bias, h_out, c_out, cus, s);
+    KVAE_SF_LAUNCH(1, grid);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

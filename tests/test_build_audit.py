@@ -3,7 +3,9 @@ cross-compiles).  The kernel pins its upper-layer weights to accumulation regist
 constraint; when the register allocator evicts such a vector it saves the pieces apart and, with
 this compiler, does not restore all of them (tools/exp/orphan_spills.py describes the pattern).
 The shipped objects must be free of it, and the checker must still find it in the form that is
-known to have it."""
+known to have it.  The pinned builds are also assembled from a listing in which every packed
+vector instruction that is directly followed by a 16-bit matrix instruction has been separated
+from it by a wait state (tools/exp/packed_before_mfma.py has the case that asked for it)."""
 import os
 import shutil
 import subprocess
@@ -15,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "kalman_vae_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CHECKER = os.path.join(ROOT, "tools", "exp", "orphan_spills.py")
+PACKED = os.path.join(ROOT, "tools", "exp", "packed_before_mfma.py")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-S", "--cuda-device-only"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
@@ -37,13 +40,42 @@ def test_upper_layer_object_has_no_spill(tmp_path):
     assert r.returncode == 0, r.stdout
 
 
+def test_pinned_lower_layer_object_has_no_spill(tmp_path):
+    """The lower layer's two-input instances, pinned like the upper layer's."""
+    r = check(listing(tmp_path, "lower2", ["-DKVAE_SF_LOWER2", "-mllvm", "-amdgpu-mfma-vgpr-form"]), "--any")
+    assert r.returncode == 0, r.stdout
+
+
+def test_packed_pairs_of_the_pinned_lower_layer_are_found_and_separated(tmp_path):
+    """The listing the compiler gives for the lower layer's two-input instances has such pairs
+    (the one that returned wrong values among them); the listing the build assembles has none,
+    and differs from the compiler's by the wait states only."""
+    raw = listing(tmp_path, "lower2", ["-DKVAE_SF_LOWER2", "-mllvm", "-amdgpu-mfma-vgpr-form"])
+    r = subprocess.run([sys.executable, PACKED, raw], capture_output=True, text=True)
+    assert r.returncode == 1 and "v_pk_" in r.stdout, r.stdout
+    padded = str(tmp_path / "lower2.padded.s")
+    subprocess.run([sys.executable, PACKED, raw, "-o", padded], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, PACKED, padded], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    a, b = open(raw).read().splitlines(), open(padded).read().splitlines()
+    assert [x for x in b if x.strip() != "s_nop 0"] == [x for x in a if x.strip() != "s_nop 0"]
+    assert len(b) > len(a)
+
+
+def test_makefile_builds_the_pinned_units_from_separated_listings():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "PADDED_UNITS := lstm_step_fused_upper lstm_step_fused_lower2" in mk
+    assert "NO_SPILL_UNITS := lstm_step_fused_upper lstm_step_fused_lower2" in mk
+
+
 def test_lower_layer_object_restores_what_it_spills(tmp_path):
     r = check(listing(tmp_path, "lower", []))
     assert r.returncode == 0, r.stdout
 
 
 def test_checker_finds_the_unrestored_piece_in_the_pinned_lower_layer(tmp_path):
-    """The reproducer: with the lower layer's weights pinned too, one dword of an evicted weight
+    """The reproducer: with the weights of the lower layer's one-input instances pinned in the
+    default build (accumulators in accumulation registers as well), one dword of an evicted weight
     vector is saved to a register that nothing reads again.  Should a later compiler restore it,
     this test fails and the pin can be tried on the lower layer again."""
     r = check(listing(tmp_path, "pinned", ["-DKVAE_SF_PIN_LOWER=1"]))

@@ -1,0 +1,66 @@
+"""Finds, in a gfx950 listing, packed vector instructions (v_pk_*) that are directly followed by
+a matrix instruction with 16-bit or 8-bit inputs, and can write the listing out again with one
+wait state between the two.
+
+What was seen: the one-step LSTM kernel, built with its weights pinned and its accumulators in
+ordinary registers, returned a wrong output gate for row 14 of the first tile of a workgroup, in
+some waves, differently from launch to launch.  The wrong accumulator element started from a
+register written by
+
+    v_pk_fma_f32 v[50:51], v[20:21], v[14:15], v[40:41] op_sel:[0,1,0]
+    v_mfma_f32_16x16x32_bf16 v[42:45], v[86:89], a[32:35], v[44:47]
+
+(the matrix instruction does not touch v50; the next but one reads v[48:51] as its accumulator
+input): lanes 48-63 of v50, the last the packed instruction writes, kept their old content.
+Edits of the listing located it: waits of 8 to 64 states anywhere else in the kernel's first
+tile (after every matrix instruction, after every other vector instruction, after every memory
+instruction with its counter waited for) left the result wrong; any one of `s_nop 0` between
+the two instructions, another vector instruction moved between them, or two v_fma_f32 in place
+of the packed one made it right, on every launch.  Other pairs of this kind in the same kernel
+give right results, so what else the failure needs is not known; the build separates them all,
+which costs one wait state each.
+
+usage: packed_before_mfma.py listing.s                 report; exit status 1 when there is a pair
+       packed_before_mfma.py listing.s -o out.s        write the listing with the pairs separated"""
+import re
+import sys
+
+OUT = sys.argv[sys.argv.index("-o") + 1] if "-o" in sys.argv else None
+lines = open(sys.argv[1]).read().splitlines()
+
+
+def code_of(line):
+    code = line.split(";")[0].strip()
+    return "" if not code or code.startswith(".") or code.endswith(":") else code
+
+
+def is_matrix(code):
+    m = re.match(r"(v_mfma_\w+|v_smfmac_\w+)\s", code)
+    # fp32 / fp64 inputs run on another path of the matrix unit; the compiler keeps no distances
+    # for them either, and the kernels that use them are bit-exact run after run
+    return bool(m) and not m.group(1).endswith(("_f32", "_f64"))
+
+
+pairs, name, prev = [], None, None          # prev = (line index, code) of the last instruction
+for no, line in enumerate(lines):
+    m = re.match(r"^(_Z\w+):", line)
+    if m:
+        name = m.group(1)
+    code = code_of(line)
+    if not code:
+        continue
+    if is_matrix(code) and prev and prev[1].startswith("v_pk_"):
+        pairs.append(no)
+        if not OUT:
+            print(f"{name}: line {prev[0] + 1}: {prev[1]}\n    line {no + 1}: {code}")
+    prev = (no, code)
+print(f"{sys.argv[1]}: {len(pairs)} packed instruction(s) directly followed by a matrix instruction")
+if OUT:
+    at = set(pairs)
+    with open(OUT, "w") as f:
+        for no, line in enumerate(lines):
+            if no in at:
+                f.write("\ts_nop 0\n")
+            f.write(line + "\n")
+    sys.exit(0)
+sys.exit(1 if pairs else 0)
