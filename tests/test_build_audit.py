@@ -64,7 +64,10 @@ def test_packed_pairs_of_the_pinned_lower_layer_are_found_and_separated(tmp_path
 
 def test_makefile_builds_the_pinned_units_from_separated_listings():
     mk = open(os.path.join(CSRC, "Makefile")).read()
-    assert "PADDED_UNITS := lstm_step_fused_upper lstm_step_fused_lower2" in mk
+    padded = mk.split("PADDED_UNITS :=")[1].splitlines()[0].split()
+    for unit in ("lstm_step_fused", "lstm_step_fused_upper", "lstm_step_fused_lower2", "rowstream_matmul",
+                 "wgrad_tn", "lstm_resident_split", "lstm_resident_tiles_split"):
+        assert unit in padded
     assert "NO_SPILL_UNITS := lstm_step_fused_upper lstm_step_fused_lower2" in mk
 
 
