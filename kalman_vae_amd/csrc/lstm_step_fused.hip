@@ -213,7 +213,10 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
     const long mine = walker < ntiles ? (ntiles - walker + walkers - 1) / walkers : 0;
     if (mine == 0) return;                       // the whole workgroup
     const long last = walker + (mine - 1) * walkers;
-    auto tile_of = [&](long k) { return k < mine ? walker + k * walkers : last; };
+    // (a 32-bit minimum: the 64-bit selection compiles to a branch, which ends the block the
+    // scheduler interleaves the tile loop's work in; the host refuses more than 2^31 tiles)
+    const int last_k = (int)(mine - 1);
+    auto tile_of = [&](long k) { return walker + (long)min((int)k, last_k) * walkers; };
     Stage s0, s1, s2;
     load_tile(tile_of(0), s0);
     load_tile(tile_of(1), s1);
@@ -431,7 +434,7 @@ extern "C" {
 int kvae_lstm128_step_fused(long B, int P, const void* x_, const void* Wx_, const void* h_prev_,
                             const void* c_prev_, const void* WhhT_, const void* bias_,
                             void* h_out_, void* c_out_, void* stream) {
-    if (B < 1 || !x_ || !Wx_ || !WhhT_ || !bias_ || !h_out_ || !c_out_ ||
+    if (B < 1 || B > (1L << 34) || !x_ || !Wx_ || !WhhT_ || !bias_ || !h_out_ || !c_out_ ||
         (h_prev_ == nullptr) != (c_prev_ == nullptr))
         return KVAE_E_BADARG;
     // wider inputs do not leave the registers for the tiles in flight: use kvae_lstm128_forward
