@@ -553,6 +553,20 @@ int kvae_lstm128_step_fused(long B, int P, const void *x, const void *Wx, const 
                             const void *c_prev, const void *WhhT, const void *bias, void *h_out,
                             void *c_out, void *stream);
 
+/* ONE time step of one layer's adjoint, without its matrix products: the masked filter calls
+ * the network once per time step (kvae/state_space_model.py:279-282), so the adjoint of
+ * torch.nn.LSTM (kvae/dynamics_parameter_network.py:46-58) is walked one step at a time, the
+ * state gradients carried by the caller.  gates (B,512): the activated i,f,g,o of the step as
+ * kvae_lstm128_forward stored them; c_prev (B,128) or NULL (zero state), c (B,128); the
+ * gradient w.r.t. this step's h is dh_a + dh_b (dh_b may be NULL: what comes from above and
+ * the recurrent part dG_{t+1} W_hh); dc_in (B,128) or NULL: the cell-state gradient from step
+ * t+1.  Outputs: dG (B,512), the gate pre-activation gradients (operands of
+ * kvae_rowstream_matmul for the gradients w.r.t. h_{t-1} and the layer input, and of
+ * kvae_lstm128_wgrad), and dc_prev (B,128).  float32, 16-byte aligned.                  */
+int kvae_lstm128_cell_backward(long B, const void *gates, const void *c_prev, const void *c,
+                               const void *dh_a, const void *dh_b, const void *dc_in, void *dG,
+                               void *dc_prev, void *stream);
+
 /* Y = X W (+ bias), the two time-batched products of that network's LSTM outside the
  * recurrences: layer 1's input projection of all steps (K = 128, N = 512, W = weight_ih_l1
  * transposed, bias = b_ih + b_hh) and the gradient layer 1 hands to layer 0 (K = 512,

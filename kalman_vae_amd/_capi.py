@@ -96,7 +96,7 @@ EXPORTS = (
     "kvae_lstm2_forward", "kvae_lstm2_backward", "kvae_lstm2_backward_blocks",
     "kvae_lstm2_prepare", "kvae_lstm2_prepared_elems",
     "kvae_lstm128_blocks", "kvae_lstm128_forward", "kvae_lstm128_backward",
-    "kvae_lstm128_backward_head", "kvae_lstm128_step_fused",
+    "kvae_lstm128_backward_head", "kvae_lstm128_step_fused", "kvae_lstm128_cell_backward",
     "kvae_lstm128_set_precision", "kvae_lstm128_get_precision", "kvae_rowstream_matmul",
     "kvae_lstm128_wgrad_slabs", "kvae_lstm128_wgrad",
     "kvae_softmax_head_forward", "kvae_softmax_head_backward",
@@ -225,6 +225,8 @@ def load():
     lib.kvae_lstm128_backward_head.restype = C.c_int
     lib.kvae_lstm128_step_fused.argtypes = [C.c_long, C.c_int] + [_vp] * 9
     lib.kvae_lstm128_step_fused.restype = C.c_int
+    lib.kvae_lstm128_cell_backward.argtypes = [C.c_long] + [_vp] * 9
+    lib.kvae_lstm128_cell_backward.restype = C.c_int
     lib.kvae_softmax_head_forward.argtypes = ([C.c_long, C.c_int, C.c_int] + [_vp] * 4
                                               + [C.c_long, _vp])
     lib.kvae_softmax_head_forward.restype = C.c_int

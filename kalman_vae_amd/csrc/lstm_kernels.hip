@@ -1030,6 +1030,52 @@ lstm2_prepare_kernel(const float* __restrict__ w_hh0, const float* __restrict__ 
     }
 }
 
+// One time step of one layer's adjoint, element by element (no matrix product): the gate
+// pre-activation gradients and the gradient handed to the previous step's cell state from
+// the gradient w.r.t. this step's h (the sum of up to two tensors: what the layer above or
+// the head sends, and the recurrent part dG_{t+1} W_hh) and the cell-state gradient arriving
+// from step t+1.  gates (B,4H) activated i,f,g,o as the forward kernels store them.
+// grid = ceil(B * H / 4 / 256), block = 256; four adjacent units per lane.
+template <int H>
+__global__ void __launch_bounds__(256)
+lstm128_cell_step_backward_kernel(long B, const float* __restrict__ gates, const float* __restrict__ c_prev,
+                          const float* __restrict__ c, const float* __restrict__ dh_a,
+                          const float* __restrict__ dh_b, const float* __restrict__ dc_in,
+                          float* __restrict__ dG, float* __restrict__ dc_prev) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= B * (H / 4)) return;
+    const long b = q / (H / 4);
+    const int u = 4 * (int)(q % (H / 4));
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](const float* ptr, long at) {
+        return ptr ? *reinterpret_cast<const float4*>(ptr + at) : zero;
+    };
+    const float4 gi = ld(gates, b * 4 * H + u), gf = ld(gates, b * 4 * H + H + u),
+                 gg = ld(gates, b * 4 * H + 2 * H + u), go = ld(gates, b * 4 * H + 3 * H + u);
+    const float4 cp = ld(c_prev, b * H + u), cc = ld(c, b * H + u);
+    const float4 da = ld(dh_a, b * H + u), db = ld(dh_b, b * H + u), dcn = ld(dc_in, b * H + u);
+    float4 oi, of, og, oo, ocp;
+    auto one = [&](float i, float f, float g, float o, float cprev, float cnow, float dh, float dc,
+                   float& di, float& df, float& dg, float& d_o, float& dcp) {
+        const float tc = tanhf_(cnow);
+        const float dct = dh * o * (1.f - tc * tc) + dc;
+        di = dct * g * i * (1.f - i);
+        df = dct * cprev * f * (1.f - f);
+        dg = dct * i * (1.f - g * g);
+        d_o = dh * tc * o * (1.f - o);
+        dcp = dct * f;
+    };
+    one(gi.x, gf.x, gg.x, go.x, cp.x, cc.x, da.x + db.x, dcn.x, oi.x, of.x, og.x, oo.x, ocp.x);
+    one(gi.y, gf.y, gg.y, go.y, cp.y, cc.y, da.y + db.y, dcn.y, oi.y, of.y, og.y, oo.y, ocp.y);
+    one(gi.z, gf.z, gg.z, go.z, cp.z, cc.z, da.z + db.z, dcn.z, oi.z, of.z, og.z, oo.z, ocp.z);
+    one(gi.w, gf.w, gg.w, go.w, cp.w, cc.w, da.w + db.w, dcn.w, oi.w, of.w, og.w, oo.w, ocp.w);
+    *reinterpret_cast<float4*>(dG + b * 4 * H + u) = oi;
+    *reinterpret_cast<float4*>(dG + b * 4 * H + H + u) = of;
+    *reinterpret_cast<float4*>(dG + b * 4 * H + 2 * H + u) = og;
+    *reinterpret_cast<float4*>(dG + b * 4 * H + 3 * H + u) = oo;
+    *reinterpret_cast<float4*>(dc_prev + b * H + u) = ocp;
+}
+
 }  // namespace kvae
 
 extern "C" {
@@ -1108,6 +1154,21 @@ int kvae_lstm2_backward(int T, int B, int P, const void* g_h1, const void* x, co
         default: return KVAE_E_UNSUPPORTED;
     }
 #undef KVAE_L2B
+    return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
+}
+
+int kvae_lstm128_cell_backward(long B, const void* gates, const void* c_prev, const void* c,
+                               const void* dh_a, const void* dh_b, const void* dc_in, void* dG,
+                               void* dc_prev, void* stream) {
+    if (B < 1 || !gates || !c || !dh_a || !dG || !dc_prev) return KVAE_E_BADARG;
+    const uintptr_t all = (uintptr_t)gates | (uintptr_t)c_prev | (uintptr_t)c | (uintptr_t)dh_a |
+                          (uintptr_t)dh_b | (uintptr_t)dc_in | (uintptr_t)dG | (uintptr_t)dc_prev;
+    if (all & 15) return KVAE_E_BADARG;
+    const long quads = B * (128 / 4);
+    hipLaunchKernelGGL((kvae::lstm128_cell_step_backward_kernel<128>), dim3((unsigned)((quads + 255) / 256)),
+                       dim3(256), 0, (hipStream_t)stream, B, (const float*)gates,
+                       (const float*)c_prev, (const float*)c, (const float*)dh_a,
+                       (const float*)dh_b, (const float*)dc_in, (float*)dG, (float*)dc_prev);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

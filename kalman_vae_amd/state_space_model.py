@@ -27,6 +27,7 @@ import torch.nn as nn
 from torch.distributions.utils import _standard_normal
 
 from . import functions as F
+from . import masked_lstm
 from .dynamics_parameter_network import make_weight_model
 from .misc import _validate_shape
 from .sample_control import SampleControl, wants_noise
@@ -310,6 +311,23 @@ class StateSpaceModel(nn.Module):
                     *self._filter_draws_split(as_, state_noise, obs_noise, L_Q, L_R),
                     symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
             if out is not None:
+                return out[:7] + (out[7][:T],)
+            self._undo_draws(log)
+        lstm, head = getattr(self.weight_model, "lstm", None), getattr(self.weight_model, "linear", None)
+        if (torch.is_grad_enabled() and as_.is_cuda and lstm is not None and head is not None
+                and getattr(self.weight_model, "use_hip_recurrence", False)
+                and self.weight_model.hidden is None):
+            # the default LSTM network under autograd: one node, the steps walked by hand in
+            # both directions
+            with self._recording_draws() as log:
+                out = masked_lstm.masked_filter_lstm_grad(
+                    as_, mask, lstm, head, A_K, C_K, Q, R, self.initial_state_mean,
+                    self.initial_state_covariance,
+                    *self._filter_draws_split(as_, state_noise, obs_noise, L_Q, L_R),
+                    symmetrize=symmetrize, burn_in=burn_in, learn_weight_model=learn_weight_model)
+            if out is not None:
+                self.weight_model.hidden = (out[8], out[9])
+                self.weight_model.count += T
                 return out[:7] + (out[7][:T],)
             self._undo_draws(log)
         if (not torch.is_grad_enabled() and as_.is_cuda
