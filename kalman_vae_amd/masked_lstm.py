@@ -202,17 +202,19 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                 # the imputation a_w = mask a + (1 - mask) (C_t (A_t m_pred + L_Q eps_z) + L_R eps_a)
                 D_a[t].addcmul_(d_aw, mask[t].unsqueeze(-1))
                 d_aimp = torch.mul(d_aw, one_minus[t].unsqueeze(-1), out=DAI[t])
-                z = torch.matmul(As[t], m_pred.unsqueeze(-1)).squeeze(-1)
+                # (per-sequence 4x4 products as multiply + sum: the batched library product of
+                # 65536 such problems takes ~0.9 ms)
+                z = (As[t] * m_pred.unsqueeze(-2)).sum(-1)
                 if eps_z is not None:
                     z = torch.addmm(z, eps_z[t], L_Q.t())
-                dz = torch.matmul(Cs[t].transpose(-1, -2), d_aimp.unsqueeze(-1)).squeeze(-1)
+                dz = (Cs[t] * d_aimp.unsqueeze(-1)).sum(-2)
                 DZ[t].copy_(dz)
                 # cotangents of the mixed matrices of step t: the external ones were consumed by
                 # this step's segment; these are consumed by the segment of step t - 1 (its
                 # second row of matrices), and after the loop for t = 0
                 torch.mul(d_aimp.unsqueeze(-1), z.unsqueeze(-2), out=gC[t])
                 torch.mul(dz.unsqueeze(-1), m_pred.unsqueeze(-2), out=gA[t])
-                back = torch.matmul(As[t].transpose(-1, -2), dz.unsqueeze(-1)).squeeze(-1)
+                back = (As[t] * dz.unsqueeze(-1)).sum(-2)
                 if t:
                     G_mn[t - 1] += back
                 else:

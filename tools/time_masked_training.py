@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Masked filter under autograd with the perceptron weight network: the single-node path
-(one launch per direction) against the step-by-step path (T one-step launches plus torch
-glue), forward + backward, HIP events.  python tools/time_masked_training.py [B ...]"""
+"""Masked filter under autograd, forward + backward, HIP events: with the perceptron weight
+network the single-node path (one launch per direction) against the step-by-step path (T
+one-step launches plus torch glue); with the default LSTM network the single-node path (the
+steps walked by hand through the library's kernels) against the step-by-step path (library
+LSTM call and autograd nodes per step).  python tools/time_masked_training.py [B ...]"""
 import os
 import sys
 
@@ -45,7 +47,14 @@ def main():
         fast = timed(step)
         ssm.in_kernel_weight_network = False
         slow = timed(step, iters=3)
-        print(f"B={B}: one launch per direction {fast:.3f} ms, step-by-step {slow:.3f} ms, "
+        print(f"B={B}: perceptron: one launch per direction {fast:.3f} ms, step-by-step {slow:.3f} ms, "
+              f"ratio {slow / fast:.1f}x", flush=True)
+        torch.manual_seed(0)
+        ssm = StateSpaceModel(2, 4, 3, "lstm").to(dev).train()
+        fast = timed(step)
+        ssm.weight_model.use_hip_recurrence = False
+        slow = timed(step, iters=3)
+        print(f"B={B}: LSTM: one node {fast:.3f} ms, step-by-step {slow:.3f} ms, "
               f"ratio {slow / fast:.1f}x", flush=True)
 
 
