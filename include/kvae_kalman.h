@@ -306,6 +306,25 @@ int kvae_impute_observation(const kvae_dims *d, const void *w, const void *A_K, 
                             const void *eps_z, const void *L_Q, const void *eps_a,
                             const void *L_R, void *a_w, void *stream);
 
+/* Adjoint of kvae_impute_observation for one time step (autograd through
+ * kvae/state_space_model.py:232-277), given the mixed matrices A_t (B,n,n), C_t (B,p,n) the
+ * filter step wrote.  The gradient w.r.t. a_w is d_aw_a + d_aw_b (d_aw_b may be NULL).
+ * d_a (B,p): mask * that gradient is ADDED.  Written: d_aimp (B,p), the gradient w.r.t. the
+ * imputed observation, and dz (B,n), w.r.t. the imputed state (their outer products with the
+ * draws, summed over sequences and steps by the caller, are the gradients of L_R and L_Q);
+ * gC (B,p,n) = d_aimp z^T and gA (B,n,n) = dz m_pred^T, the gradients w.r.t. C_t and A_t.
+ * The gradient w.r.t. m_pred, A_t^T dz, joins what the one-step filter adjoint of this step
+ * returned for its initial state (d_m_seg (B,n), d_P_seg (B,n,n)): with g_mn_prev (B,n) and
+ * g_Pn_prev (B,n,n), the cotangents of the previous step's predicted state, d_m_seg + A_t^T dz
+ * and d_P_seg are ADDED to them; with both NULL (first step) A_t^T dz is added to d_m_seg.
+ * Uses B, n, p, dtype of d.  Small state dimensions only (KVAE_E_UNSUPPORTED otherwise). */
+int kvae_impute_observation_backward(const kvae_dims *d, const void *d_aw_a, const void *d_aw_b,
+                                     const void *mask, const void *A_t, const void *C_t,
+                                     const void *m_pred, const void *eps_z, const void *L_Q,
+                                     void *d_a, void *d_aimp, void *dz, void *gC, void *gA,
+                                     void *d_m_seg, const void *d_P_seg, void *g_mn_prev,
+                                     void *g_Pn_prev, void *stream);
+
 /* The masked filter with its weight network evaluated inside the recursion, for the
  * two-layer perceptron softmax(W2 relu(W1 a + b1) + b2)
  * (kvae/dynamics_parameter_network.py:61-90 with num_layers = 2): the loop of
@@ -562,10 +581,14 @@ int kvae_lstm128_step_fused(long B, int P, const void *x, const void *Wx, const 
  * the recurrent part dG_{t+1} W_hh); dc_in (B,128) or NULL: the cell-state gradient from step
  * t+1.  Outputs: dG (B,512), the gate pre-activation gradients (operands of
  * kvae_rowstream_matmul for the gradients w.r.t. h_{t-1} and the layer input, and of
- * kvae_lstm128_wgrad), and dc_prev (B,128).  float32, 16-byte aligned.                  */
+ * kvae_lstm128_wgrad), and dc_prev (B,128).  dx (B,P) or NULL: for a layer with a narrow
+ * input (P <= 8) the gradient w.r.t. that input, dG Wih with Wih (512,P) as stored, plus
+ * dx_add (B,P) when that is given.  float32; the (B,128) and (B,512) operands 16-byte
+ * aligned.                                                                              */
 int kvae_lstm128_cell_backward(long B, const void *gates, const void *c_prev, const void *c,
                                const void *dh_a, const void *dh_b, const void *dc_in, void *dG,
-                               void *dc_prev, void *stream);
+                               void *dc_prev, const void *Wih, int P, const void *dx_add,
+                               void *dx, void *stream);
 
 /* Y = X W (+ bias), the two time-batched products of that network's LSTM outside the
  * recurrences: layer 1's input projection of all steps (K = 128, N = 512, W = weight_ih_l1

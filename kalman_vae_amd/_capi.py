@@ -88,7 +88,7 @@ EXPORTS = (
     "kvae_elbo_forward", "kvae_elbo_backward", "kvae_impute_observation",
     "kvae_kalman_loss_forward", "kvae_kalman_loss_backward", "kvae_kalman_loss_value_and_grad",
     "kvae_loss_saved_bytes",
-    "kvae_loss_supported",
+    "kvae_loss_supported", "kvae_impute_observation_backward",
     "kvae_filter_forward_masked_mlp", "kvae_predict_future",
     "kvae_filter_smooth_fused", "kvae_filter_smooth_fused_workspace_bytes",
     "kvae_filter_backward_masked_mlp", "kvae_filter_backward_masked_mlp_workspace_bytes",
@@ -225,7 +225,7 @@ def load():
     lib.kvae_lstm128_backward_head.restype = C.c_int
     lib.kvae_lstm128_step_fused.argtypes = [C.c_long, C.c_int] + [_vp] * 9
     lib.kvae_lstm128_step_fused.restype = C.c_int
-    lib.kvae_lstm128_cell_backward.argtypes = [C.c_long] + [_vp] * 9
+    lib.kvae_lstm128_cell_backward.argtypes = [C.c_long] + [_vp] * 9 + [C.c_int] + [_vp] * 3
     lib.kvae_lstm128_cell_backward.restype = C.c_int
     lib.kvae_softmax_head_forward.argtypes = ([C.c_long, C.c_int, C.c_int] + [_vp] * 4
                                               + [C.c_long, _vp])
@@ -236,6 +236,8 @@ def load():
     lib.kvae_softmax_head_backward_blocks.restype = C.c_int
     lib.kvae_impute_observation.argtypes = [C.POINTER(Dims)] + [_vp] * 12
     lib.kvae_impute_observation.restype = C.c_int
+    lib.kvae_impute_observation_backward.argtypes = [C.POINTER(Dims)] + [_vp] * 18
+    lib.kvae_impute_observation_backward.restype = C.c_int
     lib.kvae_filter_forward_masked_mlp.argtypes = [C.POINTER(Dims), C.POINTER(FilterFwd),
                                                    C.POINTER(MaskedMlp), _vp]
     lib.kvae_filter_forward_masked_mlp.restype = C.c_int

@@ -331,6 +331,84 @@ int run_impute(const ImputeArgs<R>& g, hipStream_t s) {
     return launch_status();
 }
 
+// Adjoint of that imputation for one time step, one lane per sequence, given the mixed
+// matrices A_t, C_t the filter step wrote: from the gradient w.r.t. a_w (the sum of up to two
+// tensors) the gradients w.r.t. the observation (added to d_a), the imputed observation
+// (d_aimp) and the imputed state (dz) -- the operands of the caller's sums over all steps for
+// L_R and L_Q --, the outer products that are the gradients w.r.t. C_t and A_t, and the
+// gradient w.r.t. m_pred, which joins what the filter segment of this step returned for its
+// initial state: with g_mn_prev / g_Pn_prev (the cotangents of the previous step's predicted
+// state) both are added there, without them (first step) d_m_seg takes it.
+template <typename R>
+struct ImputeBwdArgs {
+    long B;
+    const R *d_aw_a, *d_aw_b, *mask, *A_t, *C_t, *m_pred, *eps_z, *L_Q;
+    R *d_a, *d_aimp, *dz, *gC, *gA, *d_m_seg;
+    const R* d_P_seg;
+    R *g_mn_prev, *g_Pn_prev;
+};
+
+template <typename R, int N, int P>
+__global__ void __launch_bounds__(SEQ_BLOCK) impute_backward_kernel(ImputeBwdArgs<R> g) {
+    const long b = (long)blockIdx.x * SEQ_BLOCK + threadIdx.x;
+    if (b >= g.B) return;
+    R m[N], z[N], dz[N], da[P];
+    const R mu = g.mask[b];
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[j] = g.m_pred[b * N + j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        R acc = R(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += g.A_t[(b * N + i) * N + j] * m[j];
+        if (g.eps_z) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += g.L_Q[i * N + j] * g.eps_z[b * N + j];
+        }
+        z[i] = acc;
+        dz[i] = R(0);
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        const R d = g.d_aw_a[b * P + r] + (g.d_aw_b ? g.d_aw_b[b * P + r] : R(0));
+        g.d_a[b * P + r] += mu * d;
+        da[r] = (R(1) - mu) * d;
+        g.d_aimp[b * P + r] = da[r];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            dz[i] += g.C_t[(b * P + r) * N + i] * da[r];
+            g.gC[(b * P + r) * N + i] = da[r] * z[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        g.dz[b * N + i] = dz[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) g.gA[(b * N + i) * N + j] = dz[i] * m[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        R back = R(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) back += g.A_t[(b * N + i) * N + j] * dz[i];
+        if (g.g_mn_prev)
+            g.g_mn_prev[b * N + j] += g.d_m_seg[b * N + j] + back;
+        else
+            g.d_m_seg[b * N + j] += back;
+    }
+    if (g.g_Pn_prev) {
+#pragma unroll
+        for (int e = 0; e < N * N; ++e) g.g_Pn_prev[b * N * N + e] += g.d_P_seg[b * N * N + e];
+    }
+}
+
+template <typename R, int N, int P>
+int run_impute_backward(const ImputeBwdArgs<R>& g, hipStream_t s) {
+    hipLaunchKernelGGL((impute_backward_kernel<R, N, P>), dim3((unsigned)seq_blocks(g.B)),
+                       dim3(SEQ_BLOCK), 0, s, g);
+    return launch_status();
+}
+
 // Masked filter with the two-layer perceptron weight network evaluated in the loop
 // (filter_forward_masked_mlp_sequence): the whole T-step recursion of masked sequences
 // is ONE launch, where stepping the network between filter steps takes three launches
@@ -579,6 +657,29 @@ int kvae_impute_observation(const kvae_dims* d, const void* w, const void* A_K, 
     KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
 #undef KVAE_CALL
 #undef KVAE_IMPUTE
+    return KVAE_E_UNSUPPORTED;
+}
+
+int kvae_impute_observation_backward(const kvae_dims* d, const void* d_aw_a, const void* d_aw_b,
+                                     const void* mask, const void* A_t, const void* C_t,
+                                     const void* m_pred, const void* eps_z, const void* L_Q,
+                                     void* d_a, void* d_aimp, void* dz, void* gC, void* gA,
+                                     void* d_m_seg, const void* d_P_seg, void* g_mn_prev,
+                                     void* g_Pn_prev, void* stream) {
+    if (!dims_ok(d) || !d_aw_a || !mask || !A_t || !C_t || !m_pred || (eps_z && !L_Q) || !d_a ||
+        !d_aimp || !dz || !gC || !gA || !d_m_seg || (g_Pn_prev && !d_P_seg) ||
+        (g_mn_prev == nullptr) != (g_Pn_prev == nullptr))
+        return KVAE_E_BADARG;
+#define KVAE_IMPUTE_B(R)                                                                        \
+    ImputeBwdArgs<R> g{d->B,           (const R*)d_aw_a, (const R*)d_aw_b, (const R*)mask,      \
+                       (const R*)A_t,  (const R*)C_t,    (const R*)m_pred, (const R*)eps_z,     \
+                       (const R*)L_Q,  (R*)d_a,          (R*)d_aimp,       (R*)dz,              \
+                       (R*)gC,         (R*)gA,           (R*)d_m_seg,      (const R*)d_P_seg,   \
+                       (R*)g_mn_prev,  (R*)g_Pn_prev}
+#define KVAE_CALL(R, n_, p_, K_) [&] { KVAE_IMPUTE_B(R); return run_impute_backward<R, n_, p_>(g, (hipStream_t)stream); }()
+    KVAE_DIM_LIST(KVAE_DISPATCH_CASE)
+#undef KVAE_CALL
+#undef KVAE_IMPUTE_B
     return KVAE_E_UNSUPPORTED;
 }
 

@@ -1041,9 +1041,11 @@ __global__ void __launch_bounds__(256)
 lstm128_cell_step_backward_kernel(long B, const float* __restrict__ gates, const float* __restrict__ c_prev,
                           const float* __restrict__ c, const float* __restrict__ dh_a,
                           const float* __restrict__ dh_b, const float* __restrict__ dc_in,
-                          float* __restrict__ dG, float* __restrict__ dc_prev) {
+                          float* __restrict__ dG, float* __restrict__ dc_prev,
+                          const float* __restrict__ Wih, int P, const float* __restrict__ dx_add,
+                          float* __restrict__ dx) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= B * (H / 4)) return;
+    if (q >= B * (H / 4)) return;          // whole rows: the H / 4 = 32 lanes of a row leave together
     const long b = q / (H / 4);
     const int u = 4 * (int)(q % (H / 4));
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1074,6 +1076,23 @@ lstm128_cell_step_backward_kernel(long B, const float* __restrict__ gates, const
     *reinterpret_cast<float4*>(dG + b * 4 * H + 2 * H + u) = og;
     *reinterpret_cast<float4*>(dG + b * 4 * H + 3 * H + u) = oo;
     *reinterpret_cast<float4*>(dc_prev + b * H + u) = ocp;
+    if (dx) {
+        // gradient w.r.t. a narrow layer input: dx[b] = dG[b] Wih (+ dx_add[b]), Wih (4H,P);
+        // the 32 lanes of a row (half a wavefront) add their parts
+        static_assert(H == 128, "a row is 32 lanes");
+        const float4 parts[4] = {oi, of, og, oo};
+        for (int qq = 0; qq < P; ++qq) {
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* w = Wih + (long)(g * H + u) * P + qq;
+                acc += parts[g].x * w[0] + parts[g].y * w[P] + parts[g].z * w[2 * P] + parts[g].w * w[3 * P];
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 32);
+            if ((threadIdx.x & 31) == 0) dx[b * P + qq] = acc + (dx_add ? dx_add[b * P + qq] : 0.f);
+        }
+    }
 }
 
 }  // namespace kvae
@@ -1159,8 +1178,10 @@ int kvae_lstm2_backward(int T, int B, int P, const void* g_h1, const void* x, co
 
 int kvae_lstm128_cell_backward(long B, const void* gates, const void* c_prev, const void* c,
                                const void* dh_a, const void* dh_b, const void* dc_in, void* dG,
-                               void* dc_prev, void* stream) {
+                               void* dc_prev, const void* Wih, int P, const void* dx_add, void* dx,
+                               void* stream) {
     if (B < 1 || !gates || !c || !dh_a || !dG || !dc_prev) return KVAE_E_BADARG;
+    if (dx && (!Wih || P < 1 || P > 8)) return KVAE_E_BADARG;
     const uintptr_t all = (uintptr_t)gates | (uintptr_t)c_prev | (uintptr_t)c | (uintptr_t)dh_a |
                           (uintptr_t)dh_b | (uintptr_t)dc_in | (uintptr_t)dG | (uintptr_t)dc_prev;
     if (all & 15) return KVAE_E_BADARG;
@@ -1168,7 +1189,8 @@ int kvae_lstm128_cell_backward(long B, const void* gates, const void* c_prev, co
     hipLaunchKernelGGL((kvae::lstm128_cell_step_backward_kernel<128>), dim3((unsigned)((quads + 255) / 256)),
                        dim3(256), 0, (hipStream_t)stream, B, (const float*)gates,
                        (const float*)c_prev, (const float*)c, (const float*)dh_a,
-                       (const float*)dh_b, (const float*)dc_in, (float*)dG, (float*)dc_prev);
+                       (const float*)dh_b, (const float*)dc_in, (float*)dG, (float*)dc_prev,
+                       (const float*)Wih, P, (const float*)dx_add, (float*)dx);
     return hipGetLastError() == hipSuccess ? KVAE_OK : KVAE_E_LAUNCH;
 }
 

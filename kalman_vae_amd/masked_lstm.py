@@ -139,10 +139,11 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
         dG0, dG1 = new(T, B, 4 * H), new(T, B, 4 * H)
         dc0, dc1 = [new(B, H), new(B, H)], [new(B, H), new(B, H)]
         dh0_rec, dh1_rec, dh0_up, dh1_head = new(B, H), new(B, H), new(B, H), new(B, H)
+        through = new(B, p)
         head_part = new(lib.kvae_softmax_head_backward_blocks(B), K * (H + 1))
         DAI, DZ = zeros(T, B, p), zeros(T, B, n)
         wih0, whh0, wih1, whh1 = (w.contiguous() for w in (w_ih0, w_hh0, w_ih1, w_hh1))
-        one_minus = 1.0 - mask
+        g_aw = None if g_aw is None else g_aw.contiguous()
         stream = capi.current_stream_ptr()
         step_dims = [F._dims(1, B, n, p, K, dt, symmetrize, flag) for flag in (0, 1)]
         work = [F._workspace(d, capi.OP_FILTER_BWD, dev) for d in step_dims]
@@ -165,10 +166,7 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                 capi.check(lib.kvae_filter_backward(C.byref(step_dims[which]), C.byref(io),
                                                     ws_buf.data_ptr(), nbytes, stream))
                 GW[t:t + 2] += d_alpha2
-                if t:
-                    G_mn[t - 1] += d_m_in
-                    G_Pn[t - 1] += d_P_in
-                d_aw = None if g_aw is None else g_aw[t]
+                d_aw_a, d_aw_b = (None if g_aw is None else g_aw[t]), None
                 if learn:
                     # the network's call of step t: a_w[t] -> alpha[t + 1]
                     last = t == T - 1
@@ -179,46 +177,43 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                         B, gates1[t].data_ptr(), ptr(c1[t - 1] if t else None), c1[t].data_ptr(),
                         dh1_head.data_ptr(), None if last else dh1_rec.data_ptr(),
                         None if last else dc1[t & 1].data_ptr(), dG1[t].data_ptr(),
-                        dc1[(t & 1) ^ 1].data_ptr(), stream))
+                        dc1[(t & 1) ^ 1].data_ptr(), None, 0, None, None, stream))
                     if t:
                         L._rows_matmul(dG1[t], whh1, None, dh1_rec)
                     L._rows_matmul(dG1[t], wih1, None, dh0_up)
+                    # (the lower layer's kernel also forms the gradient w.r.t. its narrow input)
                     capi.check(lib.kvae_lstm128_cell_backward(
                         B, gates0[t].data_ptr(), ptr(c0[t - 1] if t else None), c0[t].data_ptr(),
                         dh0_up.data_ptr(), None if last else dh0_rec.data_ptr(),
                         None if last else dc0[t & 1].data_ptr(), dG0[t].data_ptr(),
-                        dc0[(t & 1) ^ 1].data_ptr(), stream))
+                        dc0[(t & 1) ^ 1].data_ptr(), wih0.data_ptr(), p, None, through.data_ptr(),
+                        stream))
                     if t:
                         L._rows_matmul(dG0[t], whh0, None, dh0_rec)
-                    through = dG0[t] @ wih0
-                    d_aw = through if d_aw is None else through + d_aw
-                if d_aw is None:
+                    d_aw_a, d_aw_b = through, d_aw_a
+                if d_aw_a is None:
                     # nothing arrives at the imputed observation (the weights are constants of
                     # the graph and a_w has no cotangent); the cotangents of this step's
                     # matrices are spent
                     gA[t].zero_()
                     gC[t].zero_()
+                    if t:
+                        G_mn[t - 1] += d_m_in
+                        G_Pn[t - 1] += d_P_in
                     continue
-                # the imputation a_w = mask a + (1 - mask) (C_t (A_t m_pred + L_Q eps_z) + L_R eps_a)
-                D_a[t].addcmul_(d_aw, mask[t].unsqueeze(-1))
-                d_aimp = torch.mul(d_aw, one_minus[t].unsqueeze(-1), out=DAI[t])
-                # (per-sequence 4x4 products as multiply + sum: the batched library product of
-                # 65536 such problems takes ~0.9 ms)
-                z = (As[t] * m_pred.unsqueeze(-2)).sum(-1)
-                if eps_z is not None:
-                    z = torch.addmm(z, eps_z[t], L_Q.t())
-                dz = (Cs[t] * d_aimp.unsqueeze(-1)).sum(-2)
-                DZ[t].copy_(dz)
-                # cotangents of the mixed matrices of step t: the external ones were consumed by
-                # this step's segment; these are consumed by the segment of step t - 1 (its
-                # second row of matrices), and after the loop for t = 0
-                torch.mul(d_aimp.unsqueeze(-1), z.unsqueeze(-2), out=gC[t])
-                torch.mul(dz.unsqueeze(-1), m_pred.unsqueeze(-2), out=gA[t])
-                back = (As[t] * dz.unsqueeze(-1)).sum(-2)
-                if t:
-                    G_mn[t - 1] += back
-                else:
-                    d_m_in += back
+                # the imputation a_w = mask a + (1 - mask) (C_t (A_t m_pred + L_Q eps_z) + L_R eps_a):
+                # one launch.  It leaves the cotangents of the mixed matrices of step t in gA[t],
+                # gC[t] (the external ones were consumed by this step's segment; these are
+                # consumed by the segment of step t - 1 as its second row of matrices, and after
+                # the loop for t = 0) and hands the segment's and its own gradient w.r.t. the
+                # predicted state to step t - 1
+                capi.check(lib.kvae_impute_observation_backward(
+                    C.byref(step_dims[0]), d_aw_a.data_ptr(), ptr(d_aw_b), mask[t].data_ptr(),
+                    As[t].data_ptr(), Cs[t].data_ptr(), m_pred.data_ptr(),
+                    ptr(None if eps_z is None else eps_z[t]), ptr(L_Q), D_a[t].data_ptr(),
+                    DAI[t].data_ptr(), DZ[t].data_ptr(), gC[t].data_ptr(), gA[t].data_ptr(),
+                    d_m_in.data_ptr(), d_P_in.data_ptr(), ptr(G_mn[t - 1] if t else None),
+                    ptr(G_Pn[t - 1] if t else None), stream))
             grads_net = (None,) * 10
             if learn:
                 # parameters of the two layers from the gate gradients of all steps
@@ -240,7 +235,7 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                 else:
                     dw_hh0, dw_hh1 = torch.zeros_like(w_hh0), torch.zeros_like(w_hh1)
                     dw_ih1 = d1.t() @ h0.view(R_, H)
-                dw_ih0 = d0.t() @ aw.view(R_, p)
+                dw_ih0 = L._splitk_tn(d0, aw.view(R_, p))
                 db0, db1 = d0.sum(0), d1.sum(0)
                 # the head's parameters: its adjoint over all steps at once
                 blocks = lib.kvae_softmax_head_backward_blocks(R_)
@@ -253,13 +248,15 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                 grads_net = (dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1,
                              sh[:K * H].view(K, H), sh[K * H:])
         # what the imputation of step 0 left for the matrices A(alpha_0), C(alpha_0)
-        d_A_K = dAK.sum(0) + torch.einsum("bk,bij->kij", ws[0], gA[0])
-        d_C_K = dCK.sum(0) + torch.einsum("bk,bij->kij", ws[0], gC[0])
+        # (sums of outer products as multiply + sum: these shapes make degenerate library GEMMs)
+        w0 = ws[0].t().reshape(K, B, 1, 1)
+        d_A_K = dAK.sum(0) + (w0 * gA[0]).sum(1)
+        d_C_K = dCK.sum(0) + (w0 * gC[0]).sum(1)
         d_L_Q = d_L_R = None
         if eps_z is not None:
-            d_L_Q = torch.einsum("tbi,tbj->ij", DZ, eps_z)
+            d_L_Q = (DZ.unsqueeze(-1) * eps_z.unsqueeze(-2)).sum((0, 1))
         if eps_a is not None:
-            d_L_R = torch.einsum("tbi,tbj->ij", DAI, eps_a)
+            d_L_R = (DAI.unsqueeze(-1) * eps_a.unsqueeze(-2)).sum((0, 1))
         d_m = d_m_in.sum(0) if m_dim == 1 else d_m_in
         d_P = d_P_in.sum(0) if P_dim == 2 else d_P_in
         return ((D_a, None) + grads_net + (d_A_K, d_C_K, dQ.sum(0), dR.sum(0), d_m, d_P, None,
