@@ -46,8 +46,8 @@
 // such pair in the two-input instance lost part of the packed instruction's write
 // (tools/exp/packed_before_mfma.py; the Makefile has the steps).
 // KVAE_SF_PIN_LOWER = 1 pins the weights of whatever lower-layer instance a build holds.  In the
-// default build that is miscompiled (see the pin below); the setting exists to rebuild the
-// failing form for tools/exp/orphan_spills.py.
+// default build that was miscompiled (see the pin below); the listing of the failing kernel is
+// kept as tests/golden/lstm_step_pinned_lower_gfx950.s for tools/exp/orphan_spills.py.
 #ifndef KVAE_SF_PIN_LOWER
 #ifdef KVAE_SF_LOWER2
 #define KVAE_SF_PIN_LOWER 1
@@ -139,8 +139,9 @@ lstm128_step_fused_kernel(long M, const float* __restrict__ x, const float* __re
                 // to spare registers) and restores only three of the four before the matrix
                 // instruction that reads the vector: the fourth operand register keeps its
                 // stale content, and the product is right or wrong with that content.
-                // tools/exp/orphan_spills.py finds the unrestored piece in the listing
-                // (-DKVAE_SF_PIN_LOWER=1 builds that form).  The builds that pin keep their
+                // tools/exp/orphan_spills.py finds the unrestored piece in the listing.  (Whether
+                // a pinned vector is evicted there changes with every edit of this kernel.)
+                // The builds that pin keep their
                 // accumulators in ordinary registers and the Makefile refuses their objects if
                 // the listing has any spill; the one-input instance spills even so and stays
                 // unpinned.

@@ -76,10 +76,13 @@ def test_lower_layer_object_restores_what_it_spills(tmp_path):
     assert r.returncode == 0, r.stdout
 
 
-def test_checker_finds_the_unrestored_piece_in_the_pinned_lower_layer(tmp_path):
-    """The reproducer: with the weights of the lower layer's one-input instances pinned in the
-    default build (accumulators in accumulation registers as well), one dword of an evicted weight
-    vector is saved to a register that nothing reads again.  Should a later compiler restore it,
-    this test fails and the pin can be tried on the lower layer again."""
-    r = check(listing(tmp_path, "pinned", ["-DKVAE_SF_PIN_LOWER=1"]))
+def test_checker_finds_the_unrestored_piece_in_the_pinned_lower_layer():
+    """The reproducer: the compiler's listing of the lower layer's one-input instance with its
+    weights pinned in the default build (accumulators in accumulation registers as well), kept
+    as a fixture from the day it returned wrong values: one dword of an evicted weight vector
+    is saved to a register that nothing reads again.  (Whether the allocator evicts a pinned
+    vector there changes with every edit of the kernel - today's source does not - which is
+    why the build refuses any spill in a pinned object instead of looking for this pattern
+    alone.)"""
+    r = check(os.path.join(ROOT, "tests", "golden", "lstm_step_pinned_lower_gfx950.s"))
     assert r.returncode == 1 and "never read afterwards" in r.stdout, r.stdout
