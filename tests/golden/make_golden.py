@@ -302,6 +302,14 @@ def cases():
     c["train_lstm128_f64"] = dict(tr, net="lstm", seed=35, hidden_dim=128, seeded_lstm=True, B=6)
     c["train_lstm128_f32"] = dict(tr, net="lstm", seed=35, hidden_dim=128, seeded_lstm=True, B=6,
                                   dtype="float32")
+    # masked sequences with that network under autograd (the imputation feeds the LSTM step by
+    # step): every output and every gradient, draws on both paths, burn-in, learned noise
+    c["masked_lstm128_f64"] = dict(base, net="lstm", seed=36, hidden_dim=128, seeded_lstm=True,
+                                   T=9, B=5, mask="random", train_mode=True,
+                                   state_transition="sample", observation="sample", burn_in=1,
+                                   general_noise=True, learn_noise_covariance=True)
+    c["masked_lstm128_mean_f64"] = dict(base, net="lstm", seed=37, hidden_dim=128,
+                                        seeded_lstm=True, T=8, B=4, mask="random")
     c["train_mlp_warmup_f64"] = dict(tr, net="mlp", seed=31, learn_weight_model=False, T=9)
     c["train_general_f64"] = dict(base, net="lstm", seed=32, train_mode=True,
                                   state_transition="sample", observation="sample",

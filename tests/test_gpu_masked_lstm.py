@@ -161,3 +161,21 @@ def test_module_masked_training_step_with_the_lstm_network_is_one_node(monkeypat
     for (k, p), q in zip(ssm.named_parameters(), ref.parameters()):
         if q.grad is not None and float(q.grad.abs().max()) > 0:
             assert rel_err(p.grad, q.grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["masked_lstm128_f64", "masked_lstm128_mean_f64"])
+def test_reference_fixture_goes_through_the_node(name, monkeypatch):
+    """The reference's own run of a masked sequence with its default 2 x 128 LSTM (float64
+    fixture: outputs and gradients of every parameter) replayed in float32: the module takes
+    the one-node path, and meets the reference at the library's float32 bound."""
+    from golden_util import Golden
+    from kalman_vae_amd import masked_lstm
+    from test_gpu_module_golden import compare, run_module
+    calls = []
+    real = masked_lstm.masked_filter_lstm_grad
+    monkeypatch.setattr(masked_lstm, "masked_filter_lstm_grad",
+                        lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    g = Golden(name)
+    obj, info, grads = run_module(g, torch.float32, monkeypatch)
+    assert calls == [1]
+    compare(g, obj, info, grads, 1e-4)
