@@ -126,7 +126,9 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
         K, n = A_K.shape[0], A_K.shape[1]
         dt, dev = a.dtype, a.device
         new = lambda *s: torch.empty(s, dtype=dt, device=dev)
-        zeros = lambda *s: torch.zeros(s, dtype=dt, device=dev)
+        # (filled by a kernel: torch.zeros is a memset, whose replay order inside a captured
+        # graph is not reliable on this ROCm version, see graphed.py)
+        zeros = lambda *s: torch.full(s, 0.0, dtype=dt, device=dev)
         own = lambda g, *s: zeros(*s) if g is None else g.contiguous().clone()
         ro = lambda g, *s: zeros(*s) if g is None else g.contiguous()
         G_m, G_P = ro(g_m, T, B, n), ro(g_P, T, B, n, n)                  # read only
@@ -195,8 +197,8 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                     # nothing arrives at the imputed observation (the weights are constants of
                     # the graph and a_w has no cotangent); the cotangents of this step's
                     # matrices are spent
-                    gA[t].zero_()
-                    gC[t].zero_()
+                    gA[t].fill_(0.0)
+                    gC[t].fill_(0.0)
                     if t:
                         G_mn[t - 1] += d_m_in
                         G_Pn[t - 1] += d_P_in
@@ -233,10 +235,12 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                         (d0[B:], h0[:-1].reshape(-1, H)), (d1, h0.reshape(R_, H)),
                         (d1[B:], h1[:-1].reshape(-1, H))])
                 else:
-                    dw_hh0, dw_hh1 = torch.zeros_like(w_hh0), torch.zeros_like(w_hh1)
+                    dw_hh0, dw_hh1 = torch.full_like(w_hh0, 0.0), torch.full_like(w_hh1, 0.0)
                     dw_ih1 = d1.t() @ h0.view(R_, H)
                 dw_ih0 = L._splitk_tn(d0, aw.view(R_, p))
-                db0, db1 = d0.sum(0), d1.sum(0)
+                # (the library's column sum: torch's many-row reduction zeroes a semaphore with a
+                # memset, which a captured graph does not replay reliably here)
+                db0, db1 = capi.column_sum_tall(d0), capi.column_sum_tall(d1)
                 # the head's parameters: its adjoint over all steps at once
                 blocks = lib.kvae_softmax_head_backward_blocks(R_)
                 part = new(blocks, K * (H + 1))
@@ -249,14 +253,15 @@ class MaskedFilterLSTMFunction(torch.autograd.Function):
                              sh[:K * H].view(K, H), sh[K * H:])
         # what the imputation of step 0 left for the matrices A(alpha_0), C(alpha_0)
         # (sums of outer products as multiply + sum: these shapes make degenerate library GEMMs)
-        w0 = ws[0].t().reshape(K, B, 1, 1)
-        d_A_K = dAK.sum(0) + (w0 * gA[0]).sum(1)
-        d_C_K = dCK.sum(0) + (w0 * gC[0]).sum(1)
+        w0 = ws[0].reshape(B, K, 1, 1)
+        tall = lambda x, *shape: capi.column_sum_tall(x.reshape(x.shape[0], -1)).view(*shape)
+        d_A_K = dAK.sum(0) + tall(w0 * gA[0].unsqueeze(1), K, n, n)
+        d_C_K = dCK.sum(0) + tall(w0 * gC[0].unsqueeze(1), K, p, n)
         d_L_Q = d_L_R = None
         if eps_z is not None:
-            d_L_Q = (DZ.unsqueeze(-1) * eps_z.unsqueeze(-2)).sum((0, 1))
+            d_L_Q = tall((DZ.unsqueeze(-1) * eps_z.unsqueeze(-2)).view(T * B, n * n), n, n)
         if eps_a is not None:
-            d_L_R = (DAI.unsqueeze(-1) * eps_a.unsqueeze(-2)).sum((0, 1))
+            d_L_R = tall((DAI.unsqueeze(-1) * eps_a.unsqueeze(-2)).view(T * B, p * p), p, p)
         d_m = d_m_in.sum(0) if m_dim == 1 else d_m_in
         d_P = d_P_in.sum(0) if P_dim == 2 else d_P_in
         return ((D_a, None) + grads_net + (d_A_K, d_C_K, dQ.sum(0), dR.sum(0), d_m, d_P, None,
