@@ -2,7 +2,17 @@
 a matrix instruction with 16-bit or 8-bit inputs, and can write the listing out again with one
 wait state between the two.
 
-What was seen: the one-step LSTM kernel, built with its weights pinned and its accumulators in
+The hazard (tools/exp/pk_mfma_repro.hip reproduces it in isolation; its output is
+profiles/r03_pk_mfma_repro.txt): a packed fp32 instruction (v_pk_fma_f32, v_pk_mul_f32,
+v_pk_add_f32) whose op_sel lets the LOW result take the HIGH half of its second source operand,
+directly followed by a bf16 matrix instruction (16x16x32 or 32x32x16), computes the low result of
+lanes 48-63 -- the last quarter the packed instruction works on -- with that operand read as zero,
+in about every second execution.  Not with op_sel on the first or third operand, not with
+op_sel_hi, not before a matrix instruction with fp32 inputs or any other instruction, not when the
+matrix instruction comes first; any instruction between the two (s_nop 0, v_nop) avoids it.
+hipcc (ROCm 7.2.0) emits such pairs: its hazard recognizer has no rule for them.
+
+How it was found: the one-step LSTM kernel, built with its weights pinned and its accumulators in
 ordinary registers, returned a wrong output gate for row 14 of the first tile of a workgroup, in
 some waves, differently from launch to launch.  The wrong accumulator element started from a
 register written by
@@ -10,15 +20,13 @@ register written by
     v_pk_fma_f32 v[50:51], v[20:21], v[14:15], v[40:41] op_sel:[0,1,0]
     v_mfma_f32_16x16x32_bf16 v[42:45], v[86:89], a[32:35], v[44:47]
 
-(the matrix instruction does not touch v50; the next but one reads v[48:51] as its accumulator
-input): lanes 48-63 of v50, the last the packed instruction writes, kept their old content.
-Edits of the listing located it: waits of 8 to 64 states anywhere else in the kernel's first
-tile (after every matrix instruction, after every other vector instruction, after every memory
-instruction with its counter waited for) left the result wrong; any one of `s_nop 0` between
-the two instructions, another vector instruction moved between them, or two v_fma_f32 in place
-of the packed one made it right, on every launch.  Other pairs of this kind in the same kernel
-give right results, so what else the failure needs is not known; the build separates them all,
-which costs one wait state each.
+(one term of bias + x0 w0 + x1 w1 missing in lanes 48-63 of v50).  Edits of the listing located
+it: waits of 8 to 64 states anywhere else in the kernel's first tile left the result wrong; any
+one of `s_nop 0` between the two instructions, another vector instruction moved between them, or
+two v_fma_f32 in place of the packed one made it right, on every launch.
+
+The build separates EVERY packed instruction from a directly following 16-bit matrix instruction
+(a superset of the trigger), which costs one wait state each.
 
 usage: packed_before_mfma.py listing.s                 report; exit status 1 when there is a pair
        packed_before_mfma.py listing.s -o out.s        write the listing with the pairs separated"""

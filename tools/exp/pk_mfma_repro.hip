@@ -1,0 +1,184 @@
+// A packed fp32 instruction with an op_sel modifier that is directly followed by a matrix
+// instruction returns a wrong low result in lanes 48-63 about every second time on gfx950
+// (MI355X); one wait state between the two cures it.  hipcc -O3 emits such pairs (its hazard
+// recognizer knows no rule for them): the one-step LSTM kernel of this repository returned
+// wrong values that way (tools/exp/packed_before_mfma.py separates the pairs in the build).
+//
+// One wavefront per SIMD: blocks of 256 threads, one block per compute unit.  Every lane
+// repeats, on its own operands,
+//     <packed instruction>  d, a, b, c         ; d holds a sentinel before
+//     [<something between>]
+//     <matrix instruction>  acc, A, B, acc     ; touches none of d, a, b, c
+// and compares d with the same arithmetic done by plain v_fma_f32 / v_mul_f32 / v_add_f32.
+// Per case: wrong low and high results by group of 16 lanes, and what the wrong low results
+// are (the sentinel = nothing written, or the result the instruction would give WITHOUT its
+// op_sel).
+//
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/exp/_build/pk_mfma_repro tools/exp/pk_mfma_repro.hip
+// run:   tools/exp/_build/pk_mfma_repro [iterations]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float SENTINEL = -12345.f;
+
+struct Counts {
+    unsigned lo, hi, lo_sentinel, lo_plain;
+    unsigned cand[12];     // wrong low results that equal fma(a.lo, X, c.lo) for X = candidate i
+};
+
+#define M16 "v_mfma_f32_16x16x32_bf16 %[acc], %[A], %[B], %[acc]\n\t"
+#define M32 "v_mfma_f32_32x32x16_bf16 %[big], %[A], %[B], %[big]\n\t"
+#define MF32 "v_mfma_f32_16x16x4_f32 %[acc], %[s0], %[s1], %[acc]\n\t"
+#define TAIL "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+#define OPERANDS                                                                              \
+    : [d] "+v"(d), [acc] "+v"(acc), [big] "+v"(big), [sc] "+v"(sc)                            \
+    : [a] "v"(a), [b] "v"(b), [c] "v"(c), [A] "v"(A), [B] "v"(B), [s0] "v"(a[0]), [s1] "v"(b[0])
+
+// CASE: packed fma, lo = a[LA] * b[LB] + c[LC], hi = a[1] * b[1] + c[1]
+template <int CASE>
+__global__ void __launch_bounds__(256) repro(const float* __restrict__ in, Counts* __restrict__ out, int iters) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const float* p = in + (long)gid * 16;
+    f32x2 a = {p[0], p[1]}, b = {p[2], p[3]}, c = {p[4], p[5]};
+    bf16x8 A, B;
+    for (int j = 0; j < 8; ++j) {
+        A[j] = (__bf16)p[8 + (j & 3)];
+        B[j] = (__bf16)p[12 + (j & 3)];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x16 big = {};
+    float sc = 0.f;
+    Counts n = {};
+    for (int it = 0; it < iters; ++it) {
+        f32x2 d = {SENTINEL, SENTINEL};
+        float want_lo, want_hi, plain_lo;
+        if constexpr (CASE >= 20 && CASE < 30) {          // packed multiply
+            plain_lo = a[0] * b[0];
+            want_lo = a[0] * b[1];
+            want_hi = a[1] * b[1];
+        } else if constexpr (CASE >= 30 && CASE < 40) {   // packed add
+            plain_lo = a[0] + b[0];
+            want_lo = a[0] + b[1];
+            want_hi = a[1] + b[1];
+        } else {
+            plain_lo = __builtin_fmaf(a[0], b[0], c[0]);
+            want_hi = __builtin_fmaf(a[1], b[1], c[1]);
+            want_lo = CASE == 0 ? plain_lo
+                      : CASE == 5 ? __builtin_fmaf(a[1], b[0], c[0])        // op_sel:[1,0,0]
+                      : CASE == 6 ? __builtin_fmaf(a[0], b[0], c[1])        // op_sel:[0,0,1]
+                      : CASE == 7 ? plain_lo                                // op_sel_hi only
+                                  : __builtin_fmaf(a[0], b[1], c[0]);       // op_sel:[0,1,0]
+            if (CASE == 7) want_hi = __builtin_fmaf(a[1], b[0], c[1]);      // op_sel_hi:[1,0,1]
+        }
+        if constexpr (CASE == 0)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 1)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 2)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\ts_nop 0\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 3)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\tv_nop\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 4)      // no matrix instruction at all
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\tv_fma_f32 %[sc], %[s0], %[s1], %[sc]\n\t" TAIL OPERANDS);
+        else if constexpr (CASE == 5)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[1,0,0]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 6)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,0,1]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 7)
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel_hi:[1,0,1]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 8)      // another 16-bit matrix instruction
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" M32 TAIL OPERANDS);
+        else if constexpr (CASE == 9)      // a matrix instruction with fp32 inputs
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" MF32 TAIL OPERANDS);
+        else if constexpr (CASE == 10)     // the matrix instruction first
+            asm volatile(M16 "v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" TAIL OPERANDS);
+        else if constexpr (CASE == 21)
+            asm volatile("v_pk_mul_f32 %[d], %[a], %[b] op_sel:[0,1]\n\t" M16 TAIL OPERANDS);
+        else if constexpr (CASE == 31)
+            asm volatile("v_pk_add_f32 %[d], %[a], %[b] op_sel:[0,1]\n\t" M16 TAIL OPERANDS);
+        const bool bad = d[0] != want_lo;
+        n.lo += bad;
+        n.hi += d[1] != want_hi;
+        n.lo_sentinel += bad && d[0] == SENTINEL;
+        n.lo_plain += bad && d[0] == plain_lo;
+        if (CASE == 1 && bad) {
+            // X: the dwords of the matrix instruction's A and B operands, the other halves of
+            // the packed instruction's own operands, zero
+            const unsigned* Aw = reinterpret_cast<const unsigned*>(&A);
+            const unsigned* Bw = reinterpret_cast<const unsigned*>(&B);
+            float X[12] = {__builtin_bit_cast(float, Aw[0]), __builtin_bit_cast(float, Aw[1]),
+                           __builtin_bit_cast(float, Aw[2]), __builtin_bit_cast(float, Aw[3]),
+                           __builtin_bit_cast(float, Bw[0]), __builtin_bit_cast(float, Bw[1]),
+                           __builtin_bit_cast(float, Bw[2]), __builtin_bit_cast(float, Bw[3]),
+                           a[1], c[1], 0.f, a[0]};
+            for (int i = 0; i < 12; ++i) n.cand[i] += d[0] == __builtin_fmaf(a[0], X[i], c[0]);
+        }
+        // other operands next time (nothing can be hoisted out of the loop)
+        a[0] = a[0] * 0.999f + 1e-4f;
+        b[1] = b[1] * 1.001f - 1e-4f;
+        c[0] += 1e-3f;
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    n.hi += big[0] == SENTINEL || sc == SENTINEL;
+    out[gid] = n;
+}
+
+template <int CASE>
+void run(const char* what, const float* in, Counts* out, int blocks, int iters) {
+    hipLaunchKernelGGL(repro<CASE>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    if (hipDeviceSynchronize() != hipSuccess) exit(2);
+    std::vector<Counts> h((size_t)blocks * 256);
+    if (hipMemcpy(h.data(), out, h.size() * sizeof(Counts), hipMemcpyDeviceToHost) != hipSuccess) exit(2);
+    unsigned long lo = 0, hi = 0, sent = 0, plain = 0, by_group[4] = {0, 0, 0, 0}, cand[12] = {};
+    for (size_t i = 0; i < h.size(); ++i) {
+        lo += h[i].lo;
+        hi += h[i].hi;
+        sent += h[i].lo_sentinel;
+        plain += h[i].lo_plain;
+        by_group[(i & 63) >> 4] += h[i].lo;
+        for (int k = 0; k < 12; ++k) cand[k] += h[i].cand[k];
+    }
+    const double per = 100.0 / ((double)h.size() / 4 * iters);
+    printf("%-78s wrong low: lanes 0-15 %5.1f%%  16-31 %5.1f%%  32-47 %5.1f%%  48-63 %5.1f%%"
+           "  (sentinel %lu, result without op_sel %lu of %lu); wrong high %lu\n",
+           what, by_group[0] * per, by_group[1] * per, by_group[2] * per, by_group[3] * per, sent, plain, lo, hi);
+    if (CASE == 1) {
+        printf("    wrong low results equal to a.lo * X + c.lo with X = A[0..3]: %lu %lu %lu %lu, B[0..3]: %lu %lu %lu %lu, "
+               "a.hi: %lu, c.hi: %lu, 0: %lu, a.lo: %lu\n", cand[0], cand[1], cand[2], cand[3], cand[4], cand[5],
+               cand[6], cand[7], cand[8], cand[9], cand[10], cand[11]);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int blocks = 256, iters = argc > 1 ? atoi(argv[1]) : 20000;
+    std::vector<float> h((size_t)blocks * 256 * 16);
+    srand(1);
+    for (auto& x : h) x = (float)(rand() % 2000001) / 2000000.f - 0.5f;
+    float* in;
+    Counts* out;
+    if (hipMalloc(&in, h.size() * 4) != hipSuccess || hipMalloc(&out, (size_t)blocks * 256 * sizeof(Counts)) != hipSuccess) return 2;
+    if (hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 2;
+    printf("%d blocks of 256 lanes, %d repetitions per lane\n", blocks, iters);
+    run<0>("v_pk_fma_f32 ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<1>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<2>("v_pk_fma_f32 op_sel:[0,1,0] ; s_nop 0 ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<3>("v_pk_fma_f32 op_sel:[0,1,0] ; v_nop ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<4>("v_pk_fma_f32 op_sel:[0,1,0] ; v_fma_f32 (no matrix instruction)", in, out, blocks, iters);
+    run<5>("v_pk_fma_f32 op_sel:[1,0,0] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<6>("v_pk_fma_f32 op_sel:[0,0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<7>("v_pk_fma_f32 op_sel_hi:[1,0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<8>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_32x32x16_bf16", in, out, blocks, iters);
+    run<9>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_16x16x4_f32", in, out, blocks, iters);
+    run<10>("v_mfma_f32_16x16x32_bf16 ; v_pk_fma_f32 op_sel:[0,1,0]", in, out, blocks, iters);
+    run<21>("v_pk_mul_f32 op_sel:[0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    run<31>("v_pk_add_f32 op_sel:[0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
+    return 0;
+}
