@@ -30,7 +30,7 @@ class SteppedNet:
         return torch.softmax(self.linear(h), dim=-1)
 
 
-def run_case(n, p, K, sample, burn_in, learn, T=7, B=37, seed=0, exact=False):
+def run_case(n, p, K, sample, burn_in, learn, T=7, B=37, seed=0, exact=False, only=None):
     from kalman_vae_amd import _capi as capi
     from kalman_vae_amd import functions as F
     from kalman_vae_amd import masked_lstm
@@ -58,8 +58,9 @@ def run_case(n, p, K, sample, burn_in, learn, T=7, B=37, seed=0, exact=False):
     leaves = [f64(t).requires_grad_(True) for t in (a, A_K, C_K, Q, R, m0, P0)]
     want = O.kalman_filter(*leaves, SteppedNet(lstm64, lin64), mask=f64(mask), eps_state=f64(eps_z),
                            eps_obs=f64(eps_a), learn_weight_model=learn, burn_in=burn_in)
-    cot = {k: torch.randn_like(want[k]) for k in NAMES}
-    loss = sum((cot[k] * want[k]).sum() for k in NAMES)
+    # (only: the functional looks at these outputs alone; the others get no cotangent at all)
+    cot = {k: torch.randn_like(want[k]) if only is None or k in only else None for k in NAMES}
+    loss = sum((cot[k] * want[k]).sum() for k in NAMES if cot[k] is not None)
     net_names = [k for k, _ in lstm64.named_parameters()] + ["head.weight", "head.bias"]
     params = leaves + list(lstm64.parameters()) + [lin64.weight, lin64.bias]
     gref = torch.autograd.grad(loss, params, allow_unused=True)
@@ -79,7 +80,7 @@ def run_case(n, p, K, sample, burn_in, learn, T=7, B=37, seed=0, exact=False):
         assert out is not None
         got = dict(zip(NAMES, out[:8]))
         got["weights"] = got["weights"][:T]
-        loss_g = sum((d(cot[k]).to(dtype) * got[k]).sum() for k in NAMES)
+        loss_g = sum((d(cot[k]).to(dtype) * got[k]).sum() for k in NAMES if cot[k] is not None)
         gp = gl + list(lstm.parameters()) + [linear.weight, linear.bias]
         ggot = torch.autograd.grad(loss_g, gp, allow_unused=True)
     finally:
@@ -111,6 +112,17 @@ def run_case(n, p, K, sample, burn_in, learn, T=7, B=37, seed=0, exact=False):
 @pytest.mark.parametrize("n,p,K", [(4, 2, 3), (2, 1, 2)])
 def test_masked_lstm_filter_matches_oracle_autograd(n, p, K, sample, burn_in, learn, exact):
     run_case(n, p, K, sample, burn_in, learn, exact=exact)
+
+
+@pytest.mark.parametrize("learn", [True, False])
+@pytest.mark.parametrize("only", [("filter_means",), ("filter_next_covariances", "mat_Cs"),
+                                  ("as_for_weight",), ("weights",)])
+def test_functional_of_some_outputs_only(only, learn):
+    """Outputs without a cotangent (autograd hands the node None for them), among them the case
+    in which nothing reaches the imputed observation: detached weights and no cotangent of a_w."""
+    if only == ("weights",) and not learn:
+        pytest.skip("detached weights: nothing to differentiate")
+    run_case(4, 2, 3, True, 1, learn, only=only)
 
 
 def test_one_step_sequence():
