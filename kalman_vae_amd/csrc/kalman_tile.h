@@ -326,7 +326,11 @@ KT_DEV bool whitener(const float* __restrict__ Sigma, float* lds, Tile& LiT, flo
 }
 
 template <int N, int P>
-__device__ void elbo_forward_sequence(const ElboFwdArgs<float>& g, int b, float* lds) {
+__device__ void elbo_forward_sequence(const ElboFwdArgs<float>& g, int b, float* lds, int t0, int t1) {
+    // steps t0 .. t1 - 1 of sequence b.  The terms of different steps depend on each other
+    // only through the sample of the step before (the transition term), so a long sequence
+    // is cut into pieces that run as wavefronts of their own: a sequence per wavefront leaves
+    // two of the three wavefronts a SIMD has room for unused at 1024 sequences.
     const long B = g.B;
     int st = 0;
     Tile LiTQ, LiTR, LiT0;
@@ -339,12 +343,21 @@ __device__ void elbo_forward_sequence(const ElboFwdArgs<float>& g, int b, float*
     const float c_obs = 0.5f * (float)P * log_2pi<float>(), c_lat = 0.5f * (float)N * log_2pi<float>();
     // the covariance the step starts with is requested one step ahead: its
     // factorisation is the first thing every step waits for
-    Tile S_next = load<N, N>(g.Ps + (long)b * N * N);
+    if (t0 > 0) {
+        // the sample of the step before this piece (the piece before computes it as well)
+        const long tb = (long)(t0 - 1) * B + b;
+        const Tile S = load<N, N>(g.Ps + tb * N * N);
+        Tile LT, unused;
+        float dg;
+        chol<N, false>(S, LT, unused, dg);          // flagged by the piece that owns the step
+        zp = vload<N>(g.ms + tb * N) + tv<N>(LT, vload<N>(g.eps + tb * N));
+    }
+    Tile S_next = load<N, N>(g.Ps + ((long)t0 * B + b) * N * N);
 #pragma unroll 1
-    for (int t = 0; t < g.T; ++t) {
+    for (int t = t0; t < t1; ++t) {
         const long tb = (long)t * B + b;
         const Tile S = S_next;
-        if (t + 1 < g.T) S_next = load<N, N>(g.Ps + (tb + B) * N * N);
+        if (t + 1 < t1) S_next = load<N, N>(g.Ps + (tb + B) * N * N);
         const Tile CT = load_t<P, N>(g.Cs + tb * P * N);
         const float ms = vload<N>(g.ms + tb * N), e = vload<N>(g.eps + tb * N);
         const float a = vload<P>(g.a + tb * P);

@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "kalman_tile.h"
+#include "device_info.h"
 #include "launch_common.h"
 #include "wave_api.h"
 
@@ -20,7 +21,10 @@ constexpr int TILE_LDS_FLOATS = 32 * 33;
 template <int N, int P>
 __global__ void __launch_bounds__(64) tile_elbo_forward_kernel(ElboFwdArgs<float> g) {
     __shared__ float lds[TILE_LDS_FLOATS];
-    tile::elbo_forward_sequence<N, P>(g, blockIdx.x, lds);
+    // blockIdx.y: which piece of the sequence (gridDim.y pieces of equal length, the last shorter)
+    const int len = (g.T + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t0 = (int)blockIdx.y * len, t1 = t0 + len < g.T ? t0 + len : g.T;
+    if (t0 < t1) tile::elbo_forward_sequence<N, P>(g, blockIdx.x, lds, t0, t1);
 }
 
 template <int N, int P>
@@ -141,13 +145,25 @@ int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws
     return KVAE_E_UNSUPPORTED;
 }
 
+// Pieces a sequence's ELBO terms are cut into: enough wavefronts for three per SIMD (the forward
+// kernel's register count allows three), pieces of at least 32 steps (each piece factors one
+// covariance more than it owns).
+static unsigned elbo_pieces(const kvae_dims* d) {
+    const long simds = 4L * device_compute_units();
+    long pieces = (3 * simds + d->B - 1) / d->B;
+    if (pieces > d->T / 32) pieces = d->T / 32;
+    if (pieces > 8) pieces = 8;
+    return (unsigned)(pieces < 1 ? 1 : pieces);
+}
+
 int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
     if (!tile_supported(d->n, d->p, d->dtype)) return KVAE_E_UNSUPPORTED;
     ElboFwdArgs<float> g = make_args<float>(d, io);
     if (!aligned16({g.As, g.Cs})) return KVAE_E_UNSUPPORTED;
 #define KVAE_CASE(n_, p_)                                                                       \
     if (d->n == n_ && d->p == p_) {                                                             \
-        hipLaunchKernelGGL((tile_elbo_forward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);   \
+        hipLaunchKernelGGL((tile_elbo_forward_kernel<n_, p_>), dim3(d->B, elbo_pieces(d)),      \
+                           dim3(64), 0, s, g);                                                  \
         return launch_status();                                                                 \
     }
     KVAE_TILE_DIM_LIST(KVAE_CASE)
