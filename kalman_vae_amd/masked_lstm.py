@@ -15,8 +15,8 @@ and the backward pass walks the steps in reverse by hand:
   gradient w.r.t. the weights of step t+1 being complete - the head's and the two layers'
   adjoints of step t (kvae_softmax_head_backward, kvae_lstm128_cell_backward and three
   row-streaming products; the state gradients are carried here), then the adjoint of the
-  imputation, a dozen small tensor operations, whose gradients w.r.t. the mixed matrices of step
-  t ride into the segment of step t-1 as cotangents of its second row of matrices;
+  imputation (kvae_impute_observation_backward), whose gradients w.r.t. the mixed matrices of
+  step t ride into the segment of step t-1 as cotangents of its second row of matrices;
   after the loop: the LSTM's and the head's parameter gradients from the gate gradients of all
   steps at once, exactly as the unmasked network's backward pass forms them.
 """
