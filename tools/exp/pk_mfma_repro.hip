@@ -37,6 +37,7 @@ struct Counts {
 #define M16 "v_mfma_f32_16x16x32_bf16 %[acc], %[A], %[B], %[acc]\n\t"
 #define M32 "v_mfma_f32_32x32x16_bf16 %[big], %[A], %[B], %[big]\n\t"
 #define MF32 "v_mfma_f32_16x16x4_f32 %[acc], %[s0], %[s1], %[acc]\n\t"
+#define MF4 "v_mfma_f32_4x4x1_16b_f32 %[acc], %[s0], %[s1], %[acc]\n\t"
 #define TAIL "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
 #define OPERANDS                                                                              \
     : [d] "+v"(d), [acc] "+v"(acc), [big] "+v"(big), [sc] "+v"(sc)                            \
@@ -98,6 +99,8 @@ __global__ void __launch_bounds__(256) repro(const float* __restrict__ in, Count
             asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" M32 TAIL OPERANDS);
         else if constexpr (CASE == 9)      // a matrix instruction with fp32 inputs
             asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" MF32 TAIL OPERANDS);
+        else if constexpr (CASE == 11)     // the 4x4x1 fp32 matrix instruction of the small-state kernels
+            asm volatile("v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" MF4 TAIL OPERANDS);
         else if constexpr (CASE == 10)     // the matrix instruction first
             asm volatile(M16 "v_pk_fma_f32 %[d], %[a], %[b], %[c] op_sel:[0,1,0]\n\t" TAIL OPERANDS);
         else if constexpr (CASE == 21)
@@ -177,6 +180,7 @@ int main(int argc, char** argv) {
     run<7>("v_pk_fma_f32 op_sel_hi:[1,0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
     run<8>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_32x32x16_bf16", in, out, blocks, iters);
     run<9>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_16x16x4_f32", in, out, blocks, iters);
+    run<11>("v_pk_fma_f32 op_sel:[0,1,0] ; v_mfma_f32_4x4x1_16b_f32", in, out, blocks, iters);
     run<10>("v_mfma_f32_16x16x32_bf16 ; v_pk_fma_f32 op_sel:[0,1,0]", in, out, blocks, iters);
     run<21>("v_pk_mul_f32 op_sel:[0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
     run<31>("v_pk_add_f32 op_sel:[0,1] ; v_mfma_f32_16x16x32_bf16", in, out, blocks, iters);
