@@ -48,6 +48,46 @@ __global__ void __launch_bounds__(256) mix_dalpha_kernel(long rows, const R* bar
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
+    if constexpr (sizeof(R) * K * (LA + LC) / 64 <= 768 && LA % 256 == 0 && LC % 256 == 0) {
+        // the bases fit the registers (K (LA + LC) / 64 values per lane: 192 floats at n = 32,
+        // p = 16, K = 8): a lane keeps the basis elements of the 16-byte pieces it reads, and
+        // the loop over rows is loads and multiply-adds only (from LDS it was eight LDS reads
+        // per element loaded, 2.0 TB/s: 3.1 -> 1.15 ms at a million rows)
+        typedef R vec4 __attribute__((ext_vector_type(4)));
+        constexpr int QA = LA / 256, QC = LC / 256;          // 16-byte pieces per lane and row
+        vec4 bA[K][QA], bC[K][QC];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+                bA[k][q] = *reinterpret_cast<const vec4*>(&bases[k * LA + 4 * (lane + 64 * q)]);
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+                bC[k][q] = *reinterpret_cast<const vec4*>(&bases[K * LA + k * LC + 4 * (lane + 64 * q)]);
+        }
+        for (long r = wave0; r < rows; r += nwaves) {
+            vec4 xa[QA], xc[QC];
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+                xa[q] = *reinterpret_cast<const vec4*>(bar_As + r * LA + 4 * (lane + 64 * q));
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+                xc[q] = *reinterpret_cast<const vec4*>(bar_Cs + r * LC + 4 * (lane + 64 * q));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                R acc = R(0);
+#pragma unroll
+                for (int q = 0; q < QA; ++q)
+                    acc += xa[q].x * bA[k][q].x + xa[q].y * bA[k][q].y + xa[q].z * bA[k][q].z + xa[q].w * bA[k][q].w;
+#pragma unroll
+                for (int q = 0; q < QC; ++q)
+                    acc += xc[q].x * bC[k][q].x + xc[q].y * bC[k][q].y + xc[q].z * bC[k][q].z + xc[q].w * bC[k][q].w;
+                const R v = wave_sum<R>(acc);
+                if (lane == 0) d_alpha[r * K + k] = v;
+            }
+        }
+        return;
+    }
     for (long r = wave0; r < rows; r += nwaves) {
         R acc[K];
 #pragma unroll
@@ -78,9 +118,34 @@ __global__ void __launch_bounds__(256) mix_dbasis_kernel(long rows, const R* alp
                                                         const R* bar_As, const R* bar_Cs,
                                                         R* partial) {
     constexpr int LA = N * N, LC = P * N;
-    const int c = blockIdx.x * 256 + threadIdx.x;  // column of [bar_As | bar_Cs]
     const long r0 = (long)blockIdx.y * MIX_ROWS_PER_CHUNK;
     const long r1 = r0 + MIX_ROWS_PER_CHUNK < rows ? r0 + MIX_ROWS_PER_CHUNK : rows;
+    if constexpr (LA % 1024 == 0 && LC % 4 == 0 && sizeof(R) == 4) {
+        // large tiles: four adjacent columns per thread, 16-byte loads (1.8 -> 1.15 ms at a million rows; gridDim.x covers
+        // (LA + LC) / 4 threads; a quad of columns lies in one of the two tensors)
+        typedef R vec4 __attribute__((ext_vector_type(4)));
+        const int c4 = 4 * (blockIdx.x * 256 + threadIdx.x);
+        if (c4 >= LA + LC) return;
+        const bool inA = c4 < LA;
+        const R* src4 = inA ? bar_As + c4 : bar_Cs + (c4 - LA);
+        const long stride4 = inA ? LA : LC;
+        vec4 acc4[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc4[k] = vec4{R(0), R(0), R(0), R(0)};
+        for (long r = r0; r < r1; ++r) {
+            const vec4 x = *reinterpret_cast<const vec4*>(src4 + r * stride4);
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc4[k] += alpha[r * K + k] * x;
+        }
+        R* out4 = partial + (long)blockIdx.y * (K * (LA + LC));
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            R* dst = inA ? out4 + k * LA + c4 : out4 + K * LA + k * LC + (c4 - LA);
+            *reinterpret_cast<vec4*>(dst) = acc4[k];
+        }
+        return;
+    }
+    const int c = blockIdx.x * 256 + threadIdx.x;  // column of [bar_As | bar_Cs]
     if (c >= LA + LC) return;
     const bool isA = c < LA;
     const R* src = isA ? bar_As + c : bar_Cs + (c - LA);
