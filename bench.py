@@ -754,7 +754,9 @@ def main():
     ap.add_argument("--state-dim", type=int, default=None)
     ap.add_argument("--obs-dim", type=int, default=None)
     ap.add_argument("--bases", type=int, default=None)
-    ap.add_argument("--chunk", type=int, default=262144, help="c3: sequences per call")
+    # (a GPU has 288 GB: a shard's million sequences go through in one call - 34.1 ms in chunks
+    # of 262 144, 32.8 ms in chunks of 524 288, 32.4 ms in one; smaller chunks are slower still)
+    ap.add_argument("--chunk", type=int, default=1048576, help="c3: sequences per call")
     ap.add_argument("--image", type=int, default=64, help="c5: frame height and width")
     ap.add_argument("--kernels-only", action="store_true",
                     help="time only the six separate HIP kernels with synthetic mixing weights "
