@@ -400,34 +400,66 @@ KT_DEV Tile precision(const float* __restrict__ Sigma) {
     return Si;
 }
 
-// acc += w/2 (u u^T - Si)
-KT_DEV void cov_grad(float w, const Rows& ur, float u, const Tile& Si, Tile& acc) {
+// A tile kept in LDS (1024 floats; lane l owns slots 64 r + l): accumulators and constants
+// that would otherwise hold 16 registers each for the whole sequence.
+KT_DEV void lds_put(float* at, const Tile& X) {
     KT_UNROLL
-    for (int r = 0; r < 16; ++r) acc.v[r] += 0.5f * w * (ur.v[r] * u - Si.v[r]);
+    for (int r = 0; r < 16; ++r) at[64 * r + threadIdx.x] = X.v[r];
+}
+KT_DEV Tile lds_get(const float* at) {
+    Tile X;
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) X.v[r] = at[64 * r + threadIdx.x];
+    return X;
 }
 
+// acc (in LDS) += w/2 (u u^T - Si)
+KT_DEV void cov_grad(float w, const Rows& ur, float u, const Tile& Si, float* acc) {
+    KT_UNROLL
+    for (int r = 0; r < 16; ++r) acc[64 * r + threadIdx.x] += 0.5f * w * (ur.v[r] * u - Si.v[r]);
+}
+
+// Steps t0 .. t1 - 1 of sequence b, piece number `piece` (its parameter-gradient sums go to
+// row piece * B + b of g.partial).  The steps depend on each other only through the sample of
+// the step before and the cotangent the transition term of the step after sends back, so a
+// long sequence is cut into pieces that run as wavefronts of their own; a piece factors one
+// covariance more than it owns at either end.  acc: 3 tiles of LDS (dQ, dR, dP0).
 template <int N, int P>
-__device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float* lds) {
+__device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float* lds, float* acc,
+                                       int t0, int t1, int piece) {
     using PG = ElboParamGrads<N, P>;
     const ElboFwdArgs<float>& f = g.f;
     const long B = f.B;
     const int T = f.T;
     const int j = lane_col(), h = lane_half();
-    const Tile SiQ = precision<N>(f.Q), SiR = precision<P>(f.Rm), Si0 = precision<N>(f.P0);
+    float* const dQ = acc, * const dR = acc + 1024, * const dP0 = acc + 2048;
+    const Tile SiQ = precision<N>(f.Q), SiR = precision<P>(f.Rm);
+    lds_put(dQ, tzero());
+    lds_put(dR, tzero());
+    lds_put(dP0, tzero());
     const float m0 = vload<N>(f.m0);
-    Tile dQ = tzero(), dR = tzero(), dP0 = tzero();
     float dm0 = 0.f;
-    store<N, N>(g.d_As + ((long)T * B + b) * N * N, dQ);
-    store<P, N>(g.d_Cs + ((long)T * B + b) * P * N, dQ);
     float zn_back = 0.f;  // w_{t+1} A_{t+1}^T u_{t+1}
+    float z_top = 0.f;    // the sample of step t1, which the piece after this one owns
+    if (t1 == T) {
+        store<N, N>(g.d_As + ((long)T * B + b) * N * N, tzero());
+        store<P, N>(g.d_Cs + ((long)T * B + b) * P * N, tzero());
+    } else {
+        const long tb = (long)t1 * B + b;
+        const Tile S = load<N, N>(f.Ps + tb * N * N);
+        Tile LTn, unused;
+        float dgn;
+        chol<N, false>(S, LTn, unused, dgn);
+        z_top = vload<N>(f.ms + tb * N) + tv<N>(LTn, vload<N>(f.eps + tb * N));
+    }
     // factor, sample and noise of the pair being processed (cur) and of the
     // pair before it (prev), which the transition term needs: one factorisation
     // per iteration, at the top of the loop, for pair t - 1.
     Tile LT = tzero(), Li = tzero();
-    float z = 0.f, e = 0.f, dg = 1.f;
-    Tile S_next = load<N, N>(f.Ps + ((long)(T - 1) * B + b) * N * N);   // one step ahead
+    float z = 0.f, e = 0.f;
+    Tile S_next = load<N, N>(f.Ps + ((long)(t1 - 1) * B + b) * N * N);   // one step ahead
 #pragma unroll 1
-    for (int t = T; t >= 0; --t) {
+    for (int t = t1; t >= t0; --t) {
         Tile LTp = tzero(), Lip = tzero();
         float zp = 0.f, ep = 0.f, dgp = 1.f;
         if (t > 0) {
@@ -439,7 +471,17 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
             chol<N, true>(S, LTp, Lip, dgp);
             zp = ms + tv<N>(LTp, ep);
         }
-        if (t < T) {
+        if (t == t1 && t1 < T) {
+            // what the transition term of step t1 sends back to the sample of step t1 - 1
+            const long tb = (long)t1 * B + b;
+            float wo, wt, wp;
+            elbo_cotangents<float>(g, tb, wo, wt, wp);
+            const Tile AT = load_t<N, N>(f.As + tb * N * N);
+            const Tile A = load<N, N>(f.As + tb * N * N);
+            const float ut = tv<N>(SiQ, z_top - tv<N>(AT, zp));
+            zn_back = wt * tv<N>(A, rows_of<N>(ut));
+        }
+        if (t < t1) {
             const long tb = (long)t * B + b;
             float wo, wt, wp;
             elbo_cotangents<float>(g, tb, wo, wt, wp);
@@ -459,10 +501,11 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
             // transition term
             float ut;
             if (t == 0) {
-                ut = tv<N>(Si0, z - m0);
+                const Tile S0 = precision<N>(f.P0);
+                ut = tv<N>(S0, z - m0);
                 const Rows utr = rows_of<N>(ut);
                 dm0 += wt * ut;
-                cov_grad(wt, utr, ut, Si0, dP0);
+                cov_grad(wt, utr, ut, S0, dP0);
                 store<N, N>(g.d_As + tb * N * N, tzero());
                 zn_back = 0.f;
             } else {
@@ -500,14 +543,12 @@ __device__ void elbo_backward_sequence(const ElboBwdArgs<float>& g, int b, float
         Li = Lip;
         z = zp;
         e = ep;
-        dg = dgp;
     }
-    (void)dg;
-    float* row = g.partial + (long)b * PG::LEN;
-    store<N, N>(row + PG::OFF_Q, dQ);
-    store<P, P>(row + PG::OFF_R, dR);
+    float* row = g.partial + ((long)piece * B + b) * PG::LEN;
+    store<N, N>(row + PG::OFF_Q, lds_get(dQ));
+    store<P, P>(row + PG::OFF_R, lds_get(dR));
     vstore<N>(row + PG::OFF_M0, dm0);
-    store<N, N>(row + PG::OFF_P0, dP0);
+    store<N, N>(row + PG::OFF_P0, lds_get(dP0));
 }
 
 

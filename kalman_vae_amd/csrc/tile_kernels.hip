@@ -27,10 +27,17 @@ __global__ void __launch_bounds__(64) tile_elbo_forward_kernel(ElboFwdArgs<float
     if (t0 < t1) tile::elbo_forward_sequence<N, P>(g, blockIdx.x, lds, t0, t1);
 }
 
+// Two wavefronts per SIMD (256 registers each, 8 workgroups' LDS per compute unit): the three
+// parameter-gradient accumulators are tiles in LDS for that.
 template <int N, int P>
-__global__ void __launch_bounds__(64) tile_elbo_backward_kernel(ElboBwdArgs<float> g) {
-    __shared__ float lds[TILE_LDS_FLOATS];
-    tile::elbo_backward_sequence<N, P>(g, blockIdx.x, lds);
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+tile_elbo_backward_kernel(ElboBwdArgs<float> g) {
+    __shared__ float lds[TILE_LDS_FLOATS + 3 * 1024];
+    const int len = (g.f.T + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t0 = (int)blockIdx.y * len, t1 = t0 + len < g.f.T ? t0 + len : g.f.T;
+    // (a piece without steps still writes its row of zeros: the row sum reads every row)
+    tile::elbo_backward_sequence<N, P>(g, blockIdx.x, lds, lds + TILE_LDS_FLOATS, t0 < t1 ? t0 : t1,
+                                       t1, (int)blockIdx.y);
 }
 
 template <int N, int P>
@@ -148,12 +155,18 @@ int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws
 // Pieces a sequence's ELBO terms are cut into: enough wavefronts for three per SIMD (the forward
 // kernel's register count allows three), pieces of at least 32 steps (each piece factors one
 // covariance more than it owns).
-static unsigned elbo_pieces(const kvae_dims* d) {
+static unsigned elbo_pieces(const kvae_dims* d, int waves_per_simd = 3) {
     const long simds = 4L * device_compute_units();
-    long pieces = (3 * simds + d->B - 1) / d->B;
+    long pieces = (waves_per_simd * simds + d->B - 1) / d->B;
     if (pieces > d->T / 32) pieces = d->T / 32;
     if (pieces > 8) pieces = 8;
     return (unsigned)(pieces < 1 ? 1 : pieces);
+}
+
+// the backward kernel runs two wavefronts per SIMD; one row of parameter-gradient sums per
+// sequence and piece
+int tile_elbo_backward_pieces(const kvae_dims* d) {
+    return tile_supported(d->n, d->p, d->dtype) ? (int)elbo_pieces(d, 2) : 1;
 }
 
 int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s) {
@@ -177,11 +190,13 @@ int tile_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, si
 #define KVAE_CASE(n_, p_)                                                                        \
     if (d->n == n_ && d->p == p_) {                                                              \
         using PG = ElboParamGrads<n_, p_>;                                                       \
-        if (ws_bytes < (size_t)d->B * PG::LEN * sizeof(float)) return KVAE_E_WORKSPACE;          \
+        const unsigned pieces = elbo_pieces(d, 2);                                               \
+        if (ws_bytes < (size_t)d->B * pieces * PG::LEN * sizeof(float)) return KVAE_E_WORKSPACE; \
         ElboBwdArgs<float> g = make_args<float>(d, io, ws);                                      \
         if (!aligned16({g.f.As, g.f.Cs})) return KVAE_E_UNSUPPORTED;                             \
-        hipLaunchKernelGGL((tile_elbo_backward_kernel<n_, p_>), dim3(d->B), dim3(64), 0, s, g);  \
-        reduce_elbo_grads<float, n_, p_>(io, ws, d->B, s);                                       \
+        hipLaunchKernelGGL((tile_elbo_backward_kernel<n_, p_>), dim3(d->B, pieces), dim3(64), 0, \
+                           s, g);                                                                \
+        reduce_elbo_grads<float, n_, p_>(io, ws, (long)d->B * pieces, s);                        \
         return launch_status();                                                                  \
     }
     KVAE_TILE_DIM_LIST(KVAE_CASE)

@@ -48,6 +48,8 @@ int tile_smooth_forward(const kvae_dims* d, const kvae_smooth_fwd* io, hipStream
 int tile_smooth_backward(const kvae_dims* d, const kvae_smooth_bwd* io, void* ws, size_t ws_bytes,
                          hipStream_t s);
 int tile_elbo_forward(const kvae_dims* d, const kvae_elbo_fwd* io, hipStream_t s);
+// rows of parameter-gradient sums per sequence that tile_elbo_backward writes into its workspace
+int tile_elbo_backward_pieces(const kvae_dims* d);
 int tile_elbo_backward(const kvae_dims* d, const kvae_elbo_bwd* io, void* ws, size_t ws_bytes,
                        hipStream_t s);
 }  // namespace kvae

@@ -348,8 +348,8 @@ size_t wave_workspace_bytes(const kvae_dims* d, int op) {
         }
         case KVAE_OP_SMOOTH_BWD:
             return (size_t)d->B * (p * p) * el;
-        case KVAE_OP_ELBO_BWD:
-            return (size_t)d->B * (n * n + p * p + n + n * n) * el;
+        case KVAE_OP_ELBO_BWD:   // a row per sequence and piece (tile kernels: tile_elbo_backward)
+            return (size_t)d->B * tile_elbo_backward_pieces(d) * (n * n + p * p + n + n * n) * el;
         default:
             return 0;
     }

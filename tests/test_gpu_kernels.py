@@ -137,6 +137,8 @@ def test_tile_state16_f32(be, large_state):
                     symmetrize=False)
     KC.check_elbo(be, T=9, B=4, n=16, p=8, K=4, dtype=torch.float32, seed=44)
     KC.check_elbo(be, T=1, B=3, n=16, p=8, K=4, dtype=torch.float32, seed=45)
+    # long enough for the kernels to cut a sequence into pieces (two of 33 and 32 steps)
+    KC.check_elbo(be, T=65, B=2, n=16, p=8, K=4, dtype=torch.float32, seed=46)
 
 
 def test_wave_large_state_f32(be, large_state):
@@ -146,6 +148,8 @@ def test_wave_large_state_f32(be, large_state):
     KC.check_smooth(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=2, sample=True,
                     burn_in=2)
     KC.check_elbo(be, T=12, B=5, n=32, p=16, K=8, dtype=torch.float32, seed=3)
+    # three pieces of 34, 34 and 32 steps
+    KC.check_elbo(be, T=100, B=3, n=32, p=16, K=8, dtype=torch.float32, seed=5)
     KC.check_elbo(be, T=1, B=2, n=6, p=3, K=2, dtype=torch.float64, seed=4)
 
 
