@@ -238,8 +238,11 @@ extern "C" {
 
 int kvae_lstm128_wgrad_slabs(long R) {
     if (R < 1) return 0;
-    const long s = (R + 1023) / 1024;
-    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+    // up to 64 slabs (256 workgroups) of at least one 64-row step each: a small batch (640
+    // rows at 32 sequences of 20 steps) is ten one-step slabs, not one slab of ten steps
+    long rps = (R + 63) / 64;
+    rps = (rps + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    return (int)((R + rps - 1) / rps);
 }
 
 int kvae_lstm128_wgrad(long R, const void* dG, const void* H, long shift, void* partial,
