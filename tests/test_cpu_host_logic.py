@@ -41,6 +41,14 @@ def test_host_only_entry_points():
     assert lib.kvae_workspace_bytes(C.byref(d), capi.OP_SMOOTH_BWD) == rows * 4 * 4
     assert lib.kvae_workspace_bytes(C.byref(d), 99) == 0
     assert b"workspace" in lib.kvae_error_string(-3)
+    # slabs of the LSTM weight gradient: at most 64, each a whole number of 64-row steps,
+    # together covering the rows; a small batch gets one-step slabs
+    assert lib.kvae_lstm128_wgrad_slabs(0) == 0
+    assert lib.kvae_lstm128_wgrad_slabs(640) == 10 and lib.kvae_lstm128_wgrad_slabs(81920) == 64
+    for R in (1, 63, 64, 65, 111, 640, 4097, 7000, 81920, 1024000, 10 ** 9):
+        S = lib.kvae_lstm128_wgrad_slabs(R)
+        rps = -(-(-(-R // S)) // 64) * 64          # rows per slab as the launcher rounds them
+        assert 1 <= S <= 64 and S * rps >= R and (S - 1) * rps < R, (R, S, rps)
     # argument validation happens before any launch
     io = capi.FilterFwd()
     assert lib.kvae_filter_forward(C.byref(d), C.byref(io), None) == -1
